@@ -1,0 +1,660 @@
+/*
+ * blur_oracle.c -- CPU ORACLE for the FFT Gaussian-blur hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (blur_algorithms_amd/,
+ * include/, the C-ABI library) may include, link, call or execute this file.
+ * It is used by tests/, by __graft_entry__.smoke() and by bench.py's
+ * `cpu_baseline` leg -- and there only as the checker / the timed CPU baseline.
+ *
+ * It restates, in plain C, the arithmetic of the reference
+ * (michelerenzullo/Blur_algorithms @ 2024-11-08).  Every function cites the
+ * reference file:line it follows.
+ *
+ * PARITY STATUS
+ *   - sizing (gaussian_window, isValidSize, nearestTransformSize), kernel
+ *     generation (getGaussian), de/interleave and Reflect_101 are PINNED: they
+ *     are checked bit-for-bit against the reference's own code compiled from
+ *     /root/reference (oracle/_ref, see oracle/Makefile) and against the
+ *     known-answer values of SURVEY.md 8(c) / README.md:49-52,93-101.
+ *   - the FFT itself (pffft), flip_block and fastboxblur live in un-vendored
+ *     submodules that are absent from /root/reference (.gitmodules:1-9); the
+ *     reference ships no test or golden output for them.  For that part this
+ *     oracle is "PARITY UNPINNED": it restates the published algorithm
+ *     (unnormalised real DFT, pffft "ordered" layout, the pointwise rule of
+ *     Source.cpp:414-427 including its Nyquist-bin quirk) and is anchored on
+ *     the reference's call sites only.
+ *
+ * Two independent restatements of pffft_() live here:
+ *   ora_pffft_blur_*_f64  float64 arithmetic (exact DFT of the float32 data);
+ *                         this is the parity oracle.
+ *   ora_pffft_blur_u8c3_f32  float32, same STAGE STRUCTURE as Source.cpp:429-570
+ *                         (deinterleave, row tiles, transpose, column tiles,
+ *                         transpose, interleave) with its own radix-4/2/3/5
+ *                         real FFT and OpenMP in place of hybrid_loop; this is
+ *                         the timed CPU baseline ("port").
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORA_PI 3.14159265358979323846
+
+/* ------------------------------------------------------------------------ */
+/* A1  gaussian_window            Source.cpp:60-73                           */
+/* ------------------------------------------------------------------------ */
+int ora_gaussian_window(double sigma, int max_width)
+{
+    /* Source.cpp:64  double expression narrowed to float */
+    const float radius = (float)(sigma * sqrt(2 * log(255)) - 1);
+    /* Source.cpp:65  float arithmetic, truncation toward zero */
+    int width = (int)(radius * 2 + .5f);
+    if (max_width) width = width < max_width ? width : max_width; /* :66 */
+    if (width % 2 == 0) ++width;                                  /* :68 */
+    return width;
+}
+
+/* ------------------------------------------------------------------------ */
+/* A2  getGaussian                Source.cpp:75-102                          */
+/* kernel must hold max(width, fft_length) floats.                           */
+/* ------------------------------------------------------------------------ */
+void ora_get_gaussian(float* kernel, double sigma, int width, int fft_length)
+{
+    if (!width) width = ora_gaussian_window(sigma, 0);          /* :79 */
+    const int len = fft_length ? fft_length : width;            /* :81 */
+    /* vector::resize value-initialises the new tail; callers in the reference
+       construct the vector with `len` zeros already (Source.cpp:465). */
+    for (int k = width; k < len; ++k) kernel[k] = 0.f;
+
+    const float mid_w = (width - 1) / 2.f;                      /* :83 */
+    const double s = 2. * sigma * sigma;                        /* :84 */
+    int i = 0;
+    /* :88-89  float loop counter, y*y in float, the rest in double, result
+       stored to float BEFORE the normalisation */
+    for (float y = -mid_w; y <= mid_w; ++y, ++i)
+        kernel[i] = (float)((exp(-(y * y) / s)) / (ORA_PI * s));
+
+    double acc = 0.;                                            /* :91 */
+    for (int k = 0; k < width; ++k) acc = acc + kernel[k];
+    const double sum = 1. / acc;
+    for (int k = 0; k < width; ++k) kernel[k] = (float)(kernel[k] * sum); /* :93 */
+
+    if (fft_length) {
+        /* :99  std::rotate on reverse iterators == rotate left by width/2:
+           centre tap -> index 0, right half at 1..pad, left half at the end */
+        const int sh = width / 2;
+        float* tmp = (float*)malloc(sizeof(float) * (size_t)len);
+        for (int p = 0; p < len; ++p) tmp[p] = kernel[(p + sh) % len];
+        memcpy(kernel, tmp, sizeof(float) * (size_t)len);
+        free(tmp);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* A3  isValidSize / nearestTransformSize     Utils.hpp:141-157              */
+/* ------------------------------------------------------------------------ */
+int ora_is_valid_size(int N)
+{
+    const int N_min = 32;
+    int R = N;
+    while (R >= 5 * N_min && (R % 5) == 0) R /= 5;
+    while (R >= 3 * N_min && (R % 3) == 0) R /= 3;
+    while (R >= 2 * N_min && (R % 2) == 0) R /= 2;
+    return (R == N_min) ? 1 : 0;
+}
+
+int ora_nearest_transform_size(int N)
+{
+    const int N_min = 32;
+    if (N < N_min) N = N_min;
+    N = N_min * ((N + N_min - 1) / N_min);
+    while (!ora_is_valid_size(N)) N += N_min;
+    return N;
+}
+
+/* A4  sizing block of pffft_()   Source.cpp:434-457
+   out[0]=kSize out[1]=pad out[2]=sizes[0] (column FFT length, from rows)
+   out[3]=sizes[1] (row FFT length, from cols) out[4..5]=trailing_zeros[0..1] */
+void ora_pffft_sizing(int rows, int cols, double sigma, int out[6])
+{
+    const int kSize = ora_gaussian_window(sigma, rows > cols ? rows : cols); /* :434 */
+    const int pad = (kSize - 1) / 2;                                         /* :442, passes=1 */
+    int sizes[2] = { rows + pad * 2, cols + pad * 2 };                       /* :445 */
+    int tz[2] = { 0, 0 };
+    for (int i = 0; i < 2; ++i)
+        if (!ora_is_valid_size(sizes[i])) {                                  /* :451 */
+            const int ns = ora_nearest_transform_size(sizes[i]);
+            tz[i] = ns - sizes[i];
+            sizes[i] = ns;
+        }
+    out[0] = kSize; out[1] = pad; out[2] = sizes[0]; out[3] = sizes[1];
+    out[4] = tz[0]; out[5] = tz[1];
+}
+
+/* ------------------------------------------------------------------------ */
+/* A5 / A10  deinterleave_BGR<u8,float> / interleave_BGR<u8,float>           */
+/*           Utils.hpp:159-184, 186-210                                      */
+/* The 16 MiB blocking (Utils.hpp:164) only changes the loop order.          */
+/* ------------------------------------------------------------------------ */
+void ora_deinterleave_bgr_u8_f32(const uint8_t* in, float* B, float* G, float* R, uint32_t total)
+{
+    for (uint32_t x = 0; x < total; ++x) {   /* round = 0 for a float destination, :163 */
+        B[x] = in[x * 3 + 0];
+        G[x] = in[x * 3 + 1];
+        R[x] = in[x * 3 + 2];
+    }
+}
+
+void ora_interleave_bgr_f32_u8(const float* B, const float* G, const float* R, uint8_t* out, uint32_t total)
+{
+    /* round = 0.5f, float add, then C conversion (truncation), no clamp:
+       Utils.hpp:189,204-206.  Values outside [0,256) are UB in the reference;
+       here they go through an int so the behaviour is at least defined. */
+    for (uint32_t x = 0; x < total; ++x) {
+        out[x * 3 + 0] = (uint8_t)(int)(B[x] + 0.5f);
+        out[x * 3 + 1] = (uint8_t)(int)(G[x] + 0.5f);
+        out[x * 3 + 2] = (uint8_t)(int)(R[x] + 0.5f);
+    }
+}
+
+/* ------------------------------------------------------------------------ */
+/* Reflect_101<T,C>               Utils.hpp:212-243                          */
+/* Restated as an index map (no in-row copies), esize = sizeof(T).           */
+/* out must hold (rows+pt+pb) * (cols+pl+pr) * C elements after clamping;    */
+/* the clamped pads are returned through pads_out[4] = {top,bottom,left,right}*/
+/* ------------------------------------------------------------------------ */
+void ora_reflect_101(const void* input, void* output, int esize, int C,
+                     int pad_top, int pad_bottom, int pad_left, int pad_right,
+                     const int* original_size, int* pads_out)
+{
+    const int rows = original_size[0], cols = original_size[1];
+    if (pad_top > rows - 1) pad_top = rows - 1;        /* :217-220 */
+    if (pad_bottom > rows - 1) pad_bottom = rows - 1;
+    if (pad_left > cols - 1) pad_left = cols - 1;
+    if (pad_right > cols - 1) pad_right = cols - 1;
+    if (pads_out) { pads_out[0] = pad_top; pads_out[1] = pad_bottom; pads_out[2] = pad_left; pads_out[3] = pad_right; }
+    const int prow = rows + pad_top + pad_bottom, pcol = cols + pad_left + pad_right;
+    const char* in = (const char*)input;
+    char* out = (char*)output;
+    const size_t px = (size_t)esize * C;
+    for (int i = 0; i < prow; ++i) {
+        int sr = i - pad_top;                           /* :231-234 */
+        if (sr < 0) sr = -sr;
+        if (sr >= rows) sr = 2 * (rows - 1) - sr;
+        for (int j = 0; j < pcol; ++j) {
+            int sc = j - pad_left;                      /* :236-240 */
+            if (sc < 0) sc = -sc;
+            if (sc >= cols) sc = 2 * (cols - 1) - sc;
+            memcpy(out + ((size_t)i * pcol + j) * px, in + ((size_t)sr * cols + sc) * px, px);
+        }
+    }
+}
+
+/* A9  flip_block<float,1>(in,out,w,h): out[x*h+y] = in[y*w+x]
+       (implementation not in tree; semantics from its call sites
+       Source.cpp:540,562 -- the result is consumed as a w-row, h-column plane) */
+void ora_flip_block_f32(const float* in, float* out, int w, int h)
+{
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x)
+            out[(size_t)x * h + y] = in[(size_t)y * w + x];
+}
+
+/* A6  per-tile reflect-101 pad   Source.cpp:525-529 (rows), 549-551 (cols)
+   tile[0..N): pad reflected | L body | pad reflected | zeros                */
+static void ora_pad_tile_f32(const float* x, int L, int pad, int N, float* tile)
+{
+    for (int i = 0; i < pad; ++i) tile[i] = x[pad - i];            /* :525 */
+    for (int j = 0; j < L; ++j) tile[pad + j] = x[j];              /* :527 */
+    for (int i = 0; i < pad; ++i) tile[pad + L + i] = x[L - 2 - i];/* :529 */
+    for (int p = 2 * pad + L; p < N; ++p) tile[p] = 0.f;           /* trailing zeros */
+}
+
+void ora_pad_tile(const float* x, int L, int pad, int N, float* tile) { ora_pad_tile_f32(x, L, pad, N, tile); }
+
+/* ======================================================================== */
+/* float64 FFT (mixed radix 2/3/5, recursive DIT) -- oracle arithmetic       */
+/* ======================================================================== */
+typedef struct { double re, im; } c64;
+
+static void fft64_rec(int n, int stride, const c64* in, c64* out, const c64* tw, int twstride, c64* scratch)
+{
+    if (n == 1) { out[0] = in[0]; return; }
+    int p = (n % 2 == 0) ? 2 : (n % 3 == 0) ? 3 : (n % 5 == 0) ? 5 : n;
+    const int m = n / p;
+    if (p == n && n > 5) {            /* not expected for 2-3-5 smooth sizes: plain DFT */
+        for (int k = 0; k < n; ++k) {
+            double sr = 0, si = 0;
+            for (int j = 0; j < n; ++j) {
+                const c64 w = tw[(size_t)((long long)j * k % n) * twstride];
+                const c64 v = in[(size_t)j * stride];
+                sr += v.re * w.re - v.im * w.im; si += v.re * w.im + v.im * w.re;
+            }
+            out[k].re = sr; out[k].im = si;
+        }
+        return;
+    }
+    /* sub-transforms of the p decimated sequences go to scratch[r*m ..] */
+    for (int r = 0; r < p; ++r)
+        fft64_rec(m, stride * p, in + (size_t)r * stride, scratch + (size_t)r * m, tw, twstride * p, out + (size_t)r * m);
+    for (int k = 0; k < m; ++k)
+        for (int q = 0; q < p; ++q) {
+            const int kk = k + q * m;
+            double sr = 0, si = 0;
+            for (int r = 0; r < p; ++r) {
+                const c64 w = tw[(size_t)((long long)r * kk % n) * twstride];
+                const c64 v = scratch[(size_t)r * m + k];
+                sr += v.re * w.re - v.im * w.im; si += v.re * w.im + v.im * w.re;
+            }
+            out[kk].re = sr; out[kk].im = si;
+        }
+}
+
+typedef struct { int n; c64* tw_f; c64* tw_b; } fft64_plan;
+
+static void fft64_init(fft64_plan* p, int n)
+{
+    p->n = n;
+    p->tw_f = (c64*)malloc(sizeof(c64) * (size_t)n);
+    p->tw_b = (c64*)malloc(sizeof(c64) * (size_t)n);
+    for (int k = 0; k < n; ++k) {
+        const long double a = -2.0L * 3.14159265358979323846264338327950288L * k / n;
+        p->tw_f[k].re = (double)cosl(a); p->tw_f[k].im = (double)sinl(a);
+        p->tw_b[k].re = p->tw_f[k].re;   p->tw_b[k].im = -p->tw_f[k].im;
+    }
+}
+static void fft64_free(fft64_plan* p) { free(p->tw_f); free(p->tw_b); }
+
+/* out-of-place, unnormalised; sign<0 forward.  Recursion needs two n-sized
+   scratch areas that alternate; `out` and `scratch` play that role. */
+static void fft64_exec(const fft64_plan* p, const c64* in, c64* out, c64* scratch, int backward)
+{
+    fft64_rec(p->n, 1, in, out, backward ? p->tw_b : p->tw_f, 1, scratch);
+}
+
+/* exported for the tests: complex DFT in float64, interleaved re/im */
+void ora_fft64(int n, const double* in, double* out, int backward)
+{
+    fft64_plan p; fft64_init(&p, n);
+    c64* s = (c64*)malloc(sizeof(c64) * (size_t)n);
+    fft64_exec(&p, (const c64*)in, (c64*)out, s, backward);
+    free(s); fft64_free(&p);
+}
+
+/* Kernel multiplier table of the reference, one entry per bin 0..N/2:
+     kerf   = pffft_transform_ordered(getGaussian(...))     Source.cpp:471,485
+     m[i]   = kerf[2i] * scaler  (float * float)            Source.cpp:423
+   pffft is absent, so kerf[2i] is modelled as the correctly rounded float of
+   the exact real part of the kernel's DFT (the kernel is symmetric, its
+   spectrum real: README.md:129).  Slot 1 of the ordered layout holds the
+   NYQUIST bin but is scaled with m[0] (Source.cpp:420-425, i = 0) -- that
+   "quirk" is applied by the callers, not baked into this table. */
+void ora_kernel_multipliers(double sigma, int kSize, int N, float* m /* N/2+1 */)
+{
+    float* k = (float*)malloc(sizeof(float) * (size_t)N);
+    ora_get_gaussian(k, sigma, kSize, N);
+    const int pad = kSize / 2;
+    const float scaler = 1.f / N;                    /* Source.cpp:506-507 */
+    for (int b = 0; b <= N / 2; ++b) {
+        /* exact DFT of a symmetric real sequence with 2*pad+1 non-zero taps */
+        long double acc = k[0];
+        for (int n = 1; n <= pad; ++n) {
+            const long long t = ((long long)b * n) % N;
+            const long double c = cosl(2.0L * 3.14159265358979323846264338327950288L * (long double)t / N);
+            acc += ((long double)k[n] + (long double)k[N - n]) * c;
+        }
+        const float kerf = (float)acc;
+        m[b] = kerf * scaler;
+    }
+    free(k);
+}
+
+/* One 1D pass over `nlines` lines of length L (contiguous, stride L), float64
+   arithmetic: reflect-pad (A6), forward DFT, pointwise rule (A7) with the
+   Nyquist quirk if `quirk`, unnormalised inverse DFT, crop (A8).  Output is
+   rounded to float32 exactly once (the reference stores float32). */
+static void ora_pass_f64(const float* in, float* out, int nlines, int L, int pad, int N,
+                         const float* m, int quirk)
+{
+    fft64_plan plan; fft64_init(&plan, N);
+#pragma omp parallel
+    {
+        float* tile = (float*)malloc(sizeof(float) * (size_t)N);
+        c64* a = (c64*)malloc(sizeof(c64) * (size_t)N);
+        c64* b = (c64*)malloc(sizeof(c64) * (size_t)N);
+        c64* s = (c64*)malloc(sizeof(c64) * (size_t)N);
+#pragma omp for schedule(static)
+        for (int j = 0; j < nlines; ++j) {
+            ora_pad_tile_f32(in + (size_t)j * L, L, pad, N, tile);
+            for (int p = 0; p < N; ++p) { a[p].re = tile[p]; a[p].im = 0.; }
+            fft64_exec(&plan, a, b, s, 0);
+            for (int k = 0; k < N; ++k) {
+                int bin = k <= N / 2 ? k : N - k;
+                if (quirk && bin == N / 2) bin = 0;     /* Source.cpp:420-425, i = 0, imag slot */
+                const double mm = (double)m[bin];
+                b[k].re *= mm; b[k].im *= mm;
+            }
+            fft64_exec(&plan, b, a, s, 1);
+            for (int x = 0; x < L; ++x) out[(size_t)j * L + x] = (float)a[pad + x].re;
+        }
+        free(tile); free(a); free(b); free(s);
+    }
+    fft64_free(&plan);
+}
+
+/* pffft_() restated for ONE float plane (the per-channel body
+   Source.cpp:510-564), float64 arithmetic.  plane: rows x cols, in place.
+   inter (optional, rows*cols floats): row-pass result in row-major order
+   (what `resf` holds at Source.cpp:536, before the first flip_block).
+   Returns 0, or -1 if pad > min(rows,cols)-1 (UB in the reference,
+   README.md:33-38). */
+int ora_pffft_plane_f64(float* plane, int rows, int cols, double sigma, int quirk, float* inter)
+{
+    int sz[6]; ora_pffft_sizing(rows, cols, sigma, sz);
+    const int kSize = sz[0], pad = sz[1], N0 = sz[2], N1 = sz[3];
+    if (pad > rows - 1 || pad > cols - 1) return -1;
+    float* m_row = (float*)malloc(sizeof(float) * (size_t)(N1 / 2 + 1));
+    float* m_col = (float*)malloc(sizeof(float) * (size_t)(N0 / 2 + 1));
+    ora_kernel_multipliers(sigma, kSize, N1, m_row);
+    ora_kernel_multipliers(sigma, kSize, N0, m_col);
+    float* resf = (float*)malloc(sizeof(float) * (size_t)rows * cols);
+    float* tr = (float*)malloc(sizeof(float) * (size_t)rows * cols);
+    ora_pass_f64(plane, resf, rows, cols, pad, N1, m_row, quirk);      /* :520-537 */
+    if (inter) memcpy(inter, resf, sizeof(float) * (size_t)rows * cols);
+    ora_flip_block_f32(resf, tr, cols, rows);                          /* :540 */
+    ora_pass_f64(tr, resf, cols, rows, pad, N0, m_col, quirk);         /* :546-560 */
+    ora_flip_block_f32(resf, plane, rows, cols);                       /* :562 */
+    free(m_row); free(m_col); free(resf); free(tr);
+    return 0;
+}
+
+/* pffft_(image, sigma) restated, float64 arithmetic.  src/dst: rows*cols*3 u8
+   interleaved (may alias).  planes_out (optional, 3*rows*cols floats): the
+   float planes just before interleave_BGR (Source.cpp:567). */
+int ora_pffft_blur_u8c3_f64(const uint8_t* src, uint8_t* dst, int rows, int cols, double sigma,
+                            int quirk, float* planes_out)
+{
+    const size_t px = (size_t)rows * cols;
+    float* pl = (float*)malloc(sizeof(float) * px * 3);
+    ora_deinterleave_bgr_u8_f32(src, pl, pl + px, pl + 2 * px, (uint32_t)px);   /* :461 */
+    int rc = 0;
+    for (int c = 0; c < 3 && !rc; ++c)                                          /* :510 */
+        rc = ora_pffft_plane_f64(pl + c * px, rows, cols, sigma, quirk, NULL);
+    if (!rc) {
+        if (planes_out) memcpy(planes_out, pl, sizeof(float) * px * 3);
+        ora_interleave_bgr_f32_u8(pl, pl + px, pl + 2 * px, dst, (uint32_t)px); /* :567 */
+    }
+    free(pl);
+    return rc;
+}
+
+/* ======================================================================== */
+/* float32 "port": same stage structure as Source.cpp:429-570, own FFT.       */
+/* A pffft-shaped API (new_setup / transform_ordered / destroy_setup) so the  */
+/* body below reads like the reference's.                                     */
+/* ======================================================================== */
+typedef struct { float re, im; } c32;
+
+typedef struct ora_fft_setup {
+    int N;          /* real length */
+    int M;          /* complex length N/2 */
+    int nfac; int fac[32];
+    c32* tw;        /* exp(-2 pi i k / M), k < M */
+    c32* rtw;       /* exp(-2 pi i k / N), k <= M/2 ... k < M */
+} ora_fft_setup;
+
+ora_fft_setup* ora_fft_new_setup(int N)      /* role of pffft_new_setup(N, PFFFT_REAL), Source.cpp:477-478 */
+{
+    if (N < 2 || (N & 1)) return NULL;
+    ora_fft_setup* s = (ora_fft_setup*)calloc(1, sizeof(*s));
+    s->N = N; s->M = N / 2;
+    int r = s->M;
+    while (r % 4 == 0) { s->fac[s->nfac++] = 4; r /= 4; }
+    while (r % 2 == 0) { s->fac[s->nfac++] = 2; r /= 2; }
+    while (r % 3 == 0) { s->fac[s->nfac++] = 3; r /= 3; }
+    while (r % 5 == 0) { s->fac[s->nfac++] = 5; r /= 5; }
+    if (r != 1) { free(s); return NULL; }
+    s->tw = (c32*)malloc(sizeof(c32) * (size_t)s->M);
+    s->rtw = (c32*)malloc(sizeof(c32) * (size_t)s->M);
+    for (int k = 0; k < s->M; ++k) {
+        const double a = -2.0 * ORA_PI * k / s->M, b = -2.0 * ORA_PI * k / N;
+        s->tw[k].re = (float)cos(a); s->tw[k].im = (float)sin(a);
+        s->rtw[k].re = (float)cos(b); s->rtw[k].im = (float)sin(b);
+    }
+    return s;
+}
+
+void ora_fft_destroy_setup(ora_fft_setup* s) { if (s) { free(s->tw); free(s->rtw); free(s); } }
+
+static inline c32 cmul(c32 a, c32 b) { c32 r = { a.re * b.re - a.im * b.im, a.re * b.im + a.im * b.re }; return r; }
+static inline c32 cmulc(c32 a, c32 b) { c32 r = { a.re * b.re + a.im * b.im, a.im * b.re - a.re * b.im }; return r; } /* a*conj(b) */
+
+/* one Stockham autosort pass, radix R, forward (conj twiddles when backward) */
+static void stockham_pass(int M, int R, int Ns, const c32* in, c32* out, const c32* tw, int backward)
+{
+    const int cnt = M / R;              /* butterflies */
+    const int tws = M / (Ns * R);       /* twiddle index step */
+    const float s = backward ? -1.f : 1.f;
+    for (int blk = 0; blk < cnt / Ns; ++blk) {
+        const c32* ip = in + (size_t)blk * Ns;
+        c32* op = out + (size_t)blk * Ns * R;
+        for (int k = 0; k < Ns; ++k) {
+            c32 v[5] = { { 0.f, 0.f } };
+            for (int r = 0; r < R; ++r) {
+                c32 x = ip[k + (size_t)r * cnt];
+                if (r && Ns > 1) {
+                    c32 w = tw[(size_t)r * k * tws];
+                    x = backward ? cmulc(x, w) : cmul(x, w);
+                }
+                v[r] = x;
+            }
+            if (R == 2) {
+                c32 a = v[0], b = v[1];
+                v[0].re = a.re + b.re; v[0].im = a.im + b.im;
+                v[1].re = a.re - b.re; v[1].im = a.im - b.im;
+            } else if (R == 4) {
+                c32 a = { v[0].re + v[2].re, v[0].im + v[2].im }, b = { v[0].re - v[2].re, v[0].im - v[2].im };
+                c32 c = { v[1].re + v[3].re, v[1].im + v[3].im }, d = { v[1].re - v[3].re, v[1].im - v[3].im };
+                /* forward: -i*d = (d.im, -d.re) */
+                c32 jd = { s * d.im, -s * d.re };
+                v[0].re = a.re + c.re; v[0].im = a.im + c.im;
+                v[2].re = a.re - c.re; v[2].im = a.im - c.im;
+                v[1].re = b.re + jd.re; v[1].im = b.im + jd.im;
+                v[3].re = b.re - jd.re; v[3].im = b.im - jd.im;
+            } else if (R == 3) {
+                const float c3 = -0.5f, s3 = s * -0.86602540378443864676f;
+                c32 t1 = { v[1].re + v[2].re, v[1].im + v[2].im };
+                c32 t2 = { v[0].re + c3 * t1.re, v[0].im + c3 * t1.im };
+                c32 t3 = { s3 * (v[1].re - v[2].re), s3 * (v[1].im - v[2].im) };
+                v[0].re += t1.re; v[0].im += t1.im;
+                v[1].re = t2.re - t3.im; v[1].im = t2.im + t3.re;
+                v[2].re = t2.re + t3.im; v[2].im = t2.im - t3.re;
+            } else { /* R == 5 */
+                const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+                const float s1 = s * -0.95105651629515357212f, s2 = s * -0.58778525229247312917f;
+                c32 a1 = { v[1].re + v[4].re, v[1].im + v[4].im }, b1 = { v[1].re - v[4].re, v[1].im - v[4].im };
+                c32 a2 = { v[2].re + v[3].re, v[2].im + v[3].im }, b2 = { v[2].re - v[3].re, v[2].im - v[3].im };
+                c32 x0 = v[0];
+                c32 p1 = { x0.re + c1 * a1.re + c2 * a2.re, x0.im + c1 * a1.im + c2 * a2.im };
+                c32 p2 = { x0.re + c2 * a1.re + c1 * a2.re, x0.im + c2 * a1.im + c1 * a2.im };
+                c32 q1 = { s1 * b1.re + s2 * b2.re, s1 * b1.im + s2 * b2.im };
+                c32 q2 = { s2 * b1.re - s1 * b2.re, s2 * b1.im - s1 * b2.im };
+                v[0].re = x0.re + a1.re + a2.re; v[0].im = x0.im + a1.im + a2.im;
+                v[1].re = p1.re - q1.im; v[1].im = p1.im + q1.re;
+                v[4].re = p1.re + q1.im; v[4].im = p1.im - q1.re;
+                v[2].re = p2.re - q2.im; v[2].im = p2.im + q2.re;
+                v[3].re = p2.re + q2.im; v[3].im = p2.im - q2.re;
+            }
+            for (int r = 0; r < R; ++r) op[k + (size_t)r * Ns] = v[r];
+        }
+    }
+}
+
+/* complex FFT of length M; result lands in `a` or `b`; returns the pointer */
+static c32* cfft32(const ora_fft_setup* s, c32* a, c32* b, int backward)
+{
+    int Ns = 1;
+    c32 *in = a, *out = b;
+    for (int f = 0; f < s->nfac; ++f) {
+        stockham_pass(s->M, s->fac[f], Ns, in, out, s->tw, backward);
+        Ns *= s->fac[f];
+        c32* t = in; in = out; out = t;
+    }
+    return in;
+}
+
+/* Role of pffft_transform_ordered (Source.cpp:485,499,531,533,553,555).
+   FORWARD (direction 0): N reals -> N floats in pffft's "ordered" layout
+     [F0.re, F(N/2).re, F1.re, F1.im, ..., F(N/2-1).re, F(N/2-1).im]   
+   BACKWARD (direction 1): that layout -> N reals, UNNORMALISED (x N).
+   work: N floats of scratch.  in and out must not alias (they never do in
+   the reference: tile -> work -> tile). */
+void ora_fft_transform_ordered(const ora_fft_setup* s, const float* in, float* out, float* work, int direction)
+{
+    const int M = s->M, N = s->N;
+    c32* A = (c32*)out;
+    c32* B = (c32*)work;
+    if (direction == 0) {
+        memcpy(A, in, sizeof(float) * (size_t)N);          /* z[n] = x[2n] + i x[2n+1] */
+        c32* Z = cfft32(s, A, B, 0);
+        const c32 z0 = Z[0];
+        /* untangle pairs (k, M-k) in place:  X[k] = E[k] + w^k O[k] */
+        for (int k = 1; k <= M / 2; ++k) {
+            const c32 zk = Z[k], zm = Z[M - k];
+            const c32 zc = { zm.re, -zm.im };
+            c32 e = { 0.5f * (zk.re + zc.re), 0.5f * (zk.im + zc.im) };           /* E[k] */
+            c32 d = { 0.5f * (zk.re - zc.re), 0.5f * (zk.im - zc.im) };
+            c32 od = { d.im, -d.re };                                             /* O[k] = d / i */
+            c32 t = cmul(od, s->rtw[k]);
+            c32 xk = { e.re + t.re, e.im + t.im };
+            /* X[M-k] = conj(E[k] - w^k O[k]) */
+            c32 xm = { e.re - t.re, -(e.im - t.im) };
+            Z[k] = xk;
+            if (k != M - k) Z[M - k] = xm;
+        }
+        Z[0].re = z0.re + z0.im;                           /* F0 */
+        Z[0].im = z0.re - z0.im;                           /* F(N/2) in slot 1 */
+        if (Z != A) memcpy(A, Z, sizeof(float) * (size_t)N);
+    } else {
+        memcpy(A, in, sizeof(float) * (size_t)N);
+        const float f0 = A[0].re, fn = A[0].im;
+        /* 2 Z[k] = 2E[k] + i 2O[k],  2E = X[k] + conj X[M-k],  2 w^k O = X[k] - conj X[M-k] */
+        for (int k = 1; k <= M / 2; ++k) {
+            const c32 xk = A[k], xmm = A[M - k];
+            const c32 xc = { xmm.re, -xmm.im };
+            c32 e = { xk.re + xc.re, xk.im + xc.im };
+            c32 d = { xk.re - xc.re, xk.im - xc.im };
+            c32 t = cmulc(d, s->rtw[k]);
+            c32 od = { -t.im, t.re };
+            c32 zk = { e.re + od.re, e.im + od.im };
+            /* Z[M-k] = conj(E[k]) + i conj(O[k]) */
+            c32 zm = { e.re - od.re, -(e.im - od.im) };
+            A[k] = zk;
+            if (k != M - k) A[M - k] = zm;
+        }
+        A[0].re = f0 + fn; A[0].im = f0 - fn;
+        c32* z = cfft32(s, A, B, 1);                       /* unnormalised: yields N * x */
+        if (z != A) memcpy(A, z, sizeof(float) * (size_t)N);
+    }
+}
+
+/* pffft_sorted_optimized_convolution    Source.cpp:414-427 (literal restatement) */
+void ora_sorted_optimized_convolution(float* tile_dft, const float* kernel_dft, int size, float scaler)
+{
+    for (int i = 0; i < size / 2; i++) {
+        const int real_part_idx = 2 * i;
+        const int imag_part_idx = 2 * i + 1;
+        const float real_part_kernel_multiplier = kernel_dft[real_part_idx] * scaler;
+        tile_dft[real_part_idx] *= real_part_kernel_multiplier;
+        tile_dft[imag_part_idx] *= real_part_kernel_multiplier;
+    }
+}
+
+/* pffft_() restated in float32 with the reference's stage structure.
+   This is the timed CPU baseline ("port"; not pffft).  Source.cpp:429-570.   */
+int ora_pffft_blur_u8c3_f32(const uint8_t* src, uint8_t* dst, int rows, int cols, double sigma)
+{
+    int sz[6]; ora_pffft_sizing(rows, cols, sigma, sz);                         /* :434-457 */
+    const int kSize = sz[0], pad = sz[1], N0 = sz[2], N1 = sz[3];
+    if (pad > rows - 1 || pad > cols - 1) return -1;
+    const size_t px = (size_t)rows * cols;
+    float* temp = (float*)malloc(sizeof(float) * px * 3);                       /* :459 */
+#pragma omp parallel for schedule(static)
+    for (long x = 0; x < (long)px; ++x) {                                       /* :461 deinterleave_BGR */
+        temp[x] = src[x * 3]; temp[px + x] = src[x * 3 + 1]; temp[2 * px + x] = src[x * 3 + 2];
+    }
+    const int maxsize = N0 > N1 ? N0 : N1;
+    float* kernel_row = (float*)calloc((size_t)N1, sizeof(float));
+    float* kernel_col = (float*)calloc((size_t)N0, sizeof(float));
+    float* kerf_row = (float*)malloc(sizeof(float) * (size_t)N1);
+    float* kerf_col = (float*)malloc(sizeof(float) * (size_t)N0);
+    float* tmpw = (float*)malloc(sizeof(float) * (size_t)maxsize);
+    ora_get_gaussian(kernel_row, sigma, kSize, N1);                             /* :471 */
+    ora_fft_setup* rws = ora_fft_new_setup(N1);                                 /* :477 */
+    ora_fft_setup* cls = ora_fft_new_setup(N0);                                 /* :478 */
+    ora_fft_transform_ordered(rws, kernel_row, kerf_row, tmpw, 0);              /* :485 */
+    ora_get_gaussian(kernel_col, sigma, kSize, N0);                             /* :494 */
+    ora_fft_transform_ordered(cls, kernel_col, kerf_col, tmpw, 0);              /* :499 */
+    const float divisor_row = 1.f / N1, divisor_col = 1.f / N0;                 /* :506-507 */
+    float* resf = (float*)malloc(sizeof(float) * px);
+
+    for (int c = 0; c < 3; ++c) {                                               /* :510 */
+        float* plane = temp + (size_t)c * px;
+#pragma omp parallel
+        {
+            float* tile = (float*)malloc(sizeof(float) * (size_t)maxsize);
+            float* work = (float*)malloc(sizeof(float) * (size_t)maxsize);
+            float* tl = (float*)malloc(sizeof(float) * (size_t)maxsize);
+#pragma omp for schedule(static)
+            for (int j = 0; j < rows; ++j) {                                    /* :520 */
+                ora_pad_tile_f32(plane + (size_t)j * cols, cols, pad, N1, tile);/* :525-529 */
+                ora_fft_transform_ordered(rws, tile, work, tl, 0);              /* :531 */
+                ora_sorted_optimized_convolution(work, kerf_row, N1, divisor_row); /* :532 */
+                ora_fft_transform_ordered(rws, work, tile, tl, 1);              /* :533 */
+                memcpy(resf + (size_t)j * cols, tile + pad, sizeof(float) * (size_t)cols); /* :536 */
+            }
+#pragma omp for schedule(static) collapse(2)
+            for (int y0 = 0; y0 < rows; y0 += 64)                               /* :540 flip_block */
+                for (int x0 = 0; x0 < cols; x0 += 64)
+                    for (int y = y0; y < (y0 + 64 < rows ? y0 + 64 : rows); ++y)
+                        for (int x = x0; x < (x0 + 64 < cols ? x0 + 64 : cols); ++x)
+                            plane[(size_t)x * rows + y] = resf[(size_t)y * cols + x];
+#pragma omp for schedule(static)
+            for (int j = 0; j < cols; ++j) {                                    /* :546 */
+                ora_pad_tile_f32(plane + (size_t)j * rows, rows, pad, N0, tile);/* :549-551 */
+                ora_fft_transform_ordered(cls, tile, work, tl, 0);              /* :553 */
+                ora_sorted_optimized_convolution(work, kerf_col, N0, divisor_col); /* :554 */
+                ora_fft_transform_ordered(cls, work, tile, tl, 1);              /* :555 */
+                memcpy(resf + (size_t)j * rows, tile + pad, sizeof(float) * (size_t)rows); /* :558 */
+            }
+#pragma omp for schedule(static) collapse(2)
+            for (int y0 = 0; y0 < cols; y0 += 64)                               /* :562 flip_block */
+                for (int x0 = 0; x0 < rows; x0 += 64)
+                    for (int y = y0; y < (y0 + 64 < cols ? y0 + 64 : cols); ++y)
+                        for (int x = x0; x < (x0 + 64 < rows ? x0 + 64 : rows); ++x)
+                            plane[(size_t)x * cols + y] = resf[(size_t)y * rows + x];
+            free(tile); free(work); free(tl);
+        }
+    }
+    ora_fft_destroy_setup(cls); ora_fft_destroy_setup(rws);                     /* :565-566 */
+#pragma omp parallel for schedule(static)
+    for (long x = 0; x < (long)px; ++x) {                                       /* :567 interleave_BGR */
+        dst[x * 3 + 0] = (uint8_t)(int)(temp[x] + 0.5f);
+        dst[x * 3 + 1] = (uint8_t)(int)(temp[px + x] + 0.5f);
+        dst[x * 3 + 2] = (uint8_t)(int)(temp[2 * px + x] + 0.5f);
+    }
+    free(temp); free(kernel_row); free(kernel_col); free(kerf_row); free(kerf_col); free(tmpw); free(resf);
+    return 0;
+}
+
+int ora_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
