@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- megapixels/s of the FFT Gaussian blur (sigma=20, 4K RGB u8) on N MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one pass of the hot path (pffft_(), Source.cpp:429-570: row pass + column pass)
+over this rank's batch of FRAMES synthetic 4K RGB frames that are already resident in HBM.
+Frames are independent, so ranks shard the batch with no data-path collective (weak scaling:
+FRAMES frames per GPU per step).  Rank 0 prints ONE JSON line.
+
+Extra objects in that line:
+  roofline     -- for the slower of the two kernels: algorithmic bytes per launch
+                  (15 B/px: 3 u8 in + 12 f32 out for the row pass, 12 + 3 for the column
+                  pass) / its average launch duration from HIP events recorded
+                  on the launch stream inside the timed region; peak 8 TB/s HBM3E.
+  cpu_baseline -- the CPU port of the same path (oracle/blur_oracle.c, float32, OpenMP, same
+                  stage structure as the reference; NOT pffft) timed on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+ALG_BYTES_PER_PX_KERNEL = 15   # per kernel; 30 B/px for the frame
+
+
+def cpu_baseline(rows, cols, sigma, budget_s=8.0):
+    """time the CPU port on whole frames of the same workload for about `budget_s` seconds"""
+    import numpy as np
+    from oracle import oracle as O
+    img = np.random.default_rng(0x5EED).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    O.pffft_blur_u8c3_f32(img, sigma)          # warm-up (page faults, OpenMP pool)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.pffft_blur_u8c3_f32(img, sigma)
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s and n >= 3:
+            break
+    return {
+        "value": round(n * rows * cols / 1e6 / dt, 2),
+        "unit": "megapixels/s",
+        "cores": O.num_threads(),
+        "kind": "port",
+        "sample": "%d frames of %dx%d RGB u8, sigma=%g, %.1f s wall, float32 OpenMP port of Source.cpp:429-570 (own radix-4/2/3/5 FFT, not pffft)"
+                  % (n, cols, rows, sigma, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=8, help="frames per GPU per step (BASELINE C4: 64 frames over 8 GPUs)")
+    ap.add_argument("--rows", type=int, default=2160)
+    ap.add_argument("--cols", type=int, default=3840)
+    ap.add_argument("--sigma", type=float, default=20.0)
+    ap.add_argument("--col-group", type=int, default=0)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import blur_algorithms_amd as B
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    rows, cols, sigma, F = args.rows, args.cols, args.sigma, args.frames
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0000 + rank)
+    frames = torch.randint(0, 256, (F, rows, cols, 3), dtype=torch.uint8, device=dev, generator=g)
+    out = torch.empty_like(frames)
+    ctx = B.BlurContext(local)
+
+    def step():
+        ctx.pffft_(frames, sigma, out=out, col_group=args.col_group)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_events:
+        ctx.timing_enable(True)
+        ctx.timing(reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    tm = ctx.timing(reset=True) if not args.no_events else None
+    ctx.timing_enable(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        px = rows * cols
+        mp_total = world * args.steps * F * px / 1e6
+        rec = {
+            "metric": "megapixels/sec Gaussian blur (sigma=%g, %dx%d RGB u8)" % (sigma, cols, rows),
+            "value": round(mp_total / elapsed, 1),
+            "unit": "megapixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%dx%d RGB u8 frames, sigma=%g (kSize %d), FFT row/col lengths %d/%d, %d frames per GPU per step, device-resident"
+                            % (cols, rows, sigma, B.pffft_sizing(rows, cols, sigma)["kSize"],
+                               B.pffft_sizing(rows, cols, sigma)["N1"], B.pffft_sizing(rows, cols, sigma)["N0"], F),
+                "frames_per_gpu": F,
+                "sharding": "frames over ranks, no data-path collective",
+            },
+        }
+        frame_bytes = 2 * ALG_BYTES_PER_PX_KERNEL * px
+        rec["frame_roofline_frac"] = round((world * args.steps * F * frame_bytes / elapsed / 1e9) / (HBM_PEAK_GBS * world), 4)
+        if tm and tm["row_launches"] and tm["col_launches"]:
+            row_ms = tm["row_ms"] / tm["row_launches"]
+            col_ms = tm["col_ms"] / tm["col_launches"]
+            name, dur = ("colpass_kernel", col_ms) if col_ms >= row_ms else ("rowpass_kernel", row_ms)
+            achieved = ALG_BYTES_PER_PX_KERNEL * px / (dur * 1e-3) / 1e9
+            rec["roofline"] = {
+                "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "avg_launch_ms": {"rowpass_kernel": round(row_ms, 4), "colpass_kernel": round(col_ms, 4)},
+                "alg_bytes_per_launch": ALG_BYTES_PER_PX_KERNEL * px,
+            }
+        if world == 1 and not args.no_cpu:
+            rec["cpu_baseline"] = cpu_baseline(rows, cols, sigma)
+        print(json.dumps(rec), flush=True)
+
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,218 @@
+"""Host-side mirror of the reference's call surface for the FFT-blur hot path.
+
+Names and argument meaning follow michelerenzullo/Blur_algorithms (Source.cpp / Utils.hpp);
+the work happens in libblur_amd.so (hand-written HIP for gfx950) through the C ABI of
+include/blur_amd.h.  torch is used only to hold device memory and the stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import BlurError, BlurOpts
+
+
+def _L():
+    return _lib.load()
+
+
+# ---- sizing (host, bit-identical to the reference) -------------------------------------
+def gaussian_window(sigma, max_width=0):
+    """gaussian_window(sigma, max_width) -- Source.cpp:60-73"""
+    return _L().blur_gaussian_window(float(sigma), int(max_width))
+
+
+def getGaussian(sigma, width=0, FFT_length=0):
+    """getGaussian(kernel, sigma, width, FFT_length) -- Source.cpp:75-102; returns the kernel"""
+    w = width or gaussian_window(sigma)
+    k = np.zeros(max(w, FFT_length), np.float32)
+    rc = _L().blur_get_gaussian(k.ctypes.data, float(sigma), int(width), int(FFT_length))
+    if rc:
+        raise BlurError(rc, "getGaussian: bad arguments")
+    return k
+
+
+def isValidSize(N):
+    """isValidSize -- Utils.hpp:141-148"""
+    return _L().blur_is_valid_size(int(N))
+
+
+def nearestTransformSize(N):
+    """nearestTransformSize -- Utils.hpp:150-157"""
+    return _L().blur_nearest_transform_size(int(N))
+
+
+def pffft_sizing(rows, cols, sigma):
+    """the sizing block of pffft_() -- Source.cpp:434-457"""
+    out = (C.c_int * 6)()
+    rc = _L().blur_pffft_sizing(int(rows), int(cols), float(sigma), out)
+    if rc:
+        raise BlurError(rc, "pffft_sizing: bad arguments")
+    return dict(kSize=out[0], pad=out[1], N0=out[2], N1=out[3], tz0=out[4], tz1=out[5])
+
+
+def kernel_multipliers(sigma, ksize, n):
+    m = np.empty(n // 2 + 1, np.float32)
+    rc = _L().blur_kernel_multipliers(float(sigma), int(ksize), int(n), m.ctypes.data)
+    if rc:
+        raise BlurError(rc, "kernel_multipliers: bad arguments")
+    return m
+
+
+def fft_plan_radices(n):
+    r = (C.c_int * 16)()
+    k = _L().blur_fft_plan_radices(int(n), r)
+    return [r[i] for i in range(k)]
+
+
+# ---- the GPU context ------------------------------------------------------------------
+class BlurContext:
+    """Owns the plan / kernel-spectrum caches and the float32 workspace on one GPU
+    (role of the PFFFT_Setup pair the reference rebuilds per call, Source.cpp:477-478)."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        self._lib = _L()
+        rc = self._lib.blur_ctx_create(C.byref(self._h), int(device))
+        if rc:
+            raise BlurError(rc, self._lib.blur_last_error(None).decode())
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.blur_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise BlurError(rc, self._lib.blur_last_error(self._h).decode())
+
+    def _opts(self, nyquist_quirk=True, col_group=0):
+        o = BlurOpts()
+        self._lib.blur_opts_default(C.byref(o))
+        o.nyquist_quirk = 1 if nyquist_quirk else 0
+        o.col_group = int(col_group)
+        return o
+
+    def use_torch_stream(self):
+        import torch
+        self._check(self._lib.blur_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+
+    def set_stream(self, handle):
+        self._check(self._lib.blur_ctx_set_stream(self._h, C.c_void_p(handle)))
+
+    def synchronize(self):
+        self._check(self._lib.blur_ctx_synchronize(self._h))
+
+    def timing_enable(self, on=True):
+        self._check(self._lib.blur_ctx_timing_enable(self._h, 1 if on else 0))
+
+    def timing(self, reset=True):
+        ms = (C.c_double * 2)()
+        n = (C.c_int * 2)()
+        self._check(self._lib.blur_ctx_timing(self._h, ms, n, 1 if reset else 0))
+        return dict(row_ms=ms[0], col_ms=ms[1], row_launches=n[0], col_launches=n[1])
+
+    # -- pffft_(image, sigma): Source.cpp:429-570 -----------------------------------------
+    def pffft_(self, image, sigma, out=None, nyquist_quirk=True, col_group=0):
+        """Gaussian blur of a BGR/RGB uint8 image [rows, cols, 3] or a batch [n, rows, cols, 3].
+
+        torch CUDA tensor: asynchronous on torch's current stream, returns `out`
+        (default: in place, like the reference).  numpy array: host round trip, returns a new array.
+        """
+        o = self._opts(nyquist_quirk, col_group)
+        if isinstance(image, np.ndarray):
+            a = np.ascontiguousarray(image, np.uint8)
+            if a.ndim != 3 or a.shape[2] != 3:
+                raise ValueError("expected a uint8 image of shape [rows, cols, 3]")
+            res = np.empty_like(a)
+            self._check(self._lib.blur_gaussian_u8c3_host(self._h, a.ctypes.data, res.ctypes.data, a.shape[0], a.shape[1],
+                                                          float(sigma), C.byref(o)))
+            return res
+        import torch
+        t = image
+        if t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous() or t.shape[-1] != 3 or t.dim() not in (3, 4):
+            raise ValueError("expected a contiguous CUDA uint8 tensor [rows, cols, 3] or [n, rows, cols, 3]")
+        dst = t if out is None else out
+        if dst.shape != t.shape or dst.dtype != t.dtype or not dst.is_cuda or not dst.is_contiguous():
+            raise ValueError("out must match the input")
+        self.use_torch_stream()
+        n = 1 if t.dim() == 3 else t.shape[0]
+        rows, cols = t.shape[-3], t.shape[-2]
+        self._check(self._lib.blur_gaussian_u8c3_batch_dev(self._h, t.data_ptr(), dst.data_ptr(), n, rows, cols, float(sigma), C.byref(o)))
+        return dst
+
+    def pffft_plane(self, plane, sigma, out=None, nyquist_quirk=True, col_group=0):
+        """the per-channel body of pffft_() on one float32 plane (Source.cpp:510-564)"""
+        o = self._opts(nyquist_quirk, col_group)
+        if isinstance(plane, np.ndarray):
+            a = np.ascontiguousarray(plane, np.float32)
+            res = np.empty_like(a)
+            self._check(self._lib.blur_gaussian_f32c1_host(self._h, a.ctypes.data, res.ctypes.data, a.shape[0], a.shape[1],
+                                                           float(sigma), C.byref(o)))
+            return res
+        import torch
+        t = plane
+        if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.dim() != 2:
+            raise ValueError("expected a contiguous CUDA float32 tensor [rows, cols]")
+        dst = torch.empty_like(t) if out is None else out
+        self.use_torch_stream()
+        self._check(self._lib.blur_gaussian_f32c1_dev(self._h, t.data_ptr(), dst.data_ptr(), t.shape[0], t.shape[1], float(sigma), C.byref(o)))
+        return dst
+
+    def rowpass(self, image, sigma, nyquist_quirk=True):
+        """row pass only: uint8 [rows, cols, 3] CUDA tensor -> float32 [3, rows, cols] (Source.cpp:520-537)"""
+        import torch
+        o = self._opts(nyquist_quirk)
+        rows, cols = image.shape[0], image.shape[1]
+        planes = torch.empty((3, rows, cols), dtype=torch.float32, device=image.device)
+        self.use_torch_stream()
+        self._check(self._lib.blur_rowpass_u8c3_dev(self._h, image.data_ptr(), planes.data_ptr(), rows, cols, float(sigma), C.byref(o)))
+        return planes
+
+    # -- the pieces either side ----------------------------------------------------------------
+    def flip_block(self, plane, w, h):
+        """flip_block<float,1>(in, out, w, h) -- call sites Source.cpp:540,562"""
+        import torch
+        out = torch.empty_like(plane)
+        self.use_torch_stream()
+        self._check(self._lib.blur_flip_block_f32_dev(self._h, plane.data_ptr(), out.data_ptr(), int(w), int(h)))
+        return out
+
+    def deinterleave_BGR(self, image):
+        """deinterleave_BGR<uint8_t,float> -- Utils.hpp:159-184; returns float32 [3, total]"""
+        import torch
+        total = image.numel() // 3
+        planes = torch.empty((3, total), dtype=torch.float32, device=image.device)
+        self.use_torch_stream()
+        self._check(self._lib.blur_deinterleave_bgr_u8_f32_dev(self._h, image.data_ptr(), planes.data_ptr(), total))
+        return planes
+
+    def interleave_BGR(self, planes):
+        """interleave_BGR<uint8_t,float> -- Utils.hpp:186-210; planes float32 [3, total]"""
+        import torch
+        total = planes.shape[1]
+        out = torch.empty(total * 3, dtype=torch.uint8, device=planes.device)
+        self.use_torch_stream()
+        self._check(self._lib.blur_interleave_bgr_f32_u8_dev(self._h, planes.data_ptr(), out.data_ptr(), total))
+        return out
+
+    def fastboxblur(self, image, ksize, passes):
+        """fastboxblur(in, w, h, channels, ksize, passes), in place -- call site Source.cpp:587"""
+        if isinstance(image, np.ndarray):
+            a = np.array(image, np.uint8, order="C")
+            h, w = a.shape[:2]
+            ch = 1 if a.ndim == 2 else a.shape[2]
+            self._check(self._lib.blur_fastboxblur_u8_host(self._h, a.ctypes.data, w, h, ch, int(ksize), int(passes)))
+            return a
+        h, w = image.shape[0], image.shape[1]
+        ch = 1 if image.dim() == 2 else image.shape[2]
+        self.use_torch_stream()
+        self._check(self._lib.blur_fastboxblur_u8_dev(self._h, image.data_ptr(), w, h, ch, int(ksize), int(passes)))
+        return image

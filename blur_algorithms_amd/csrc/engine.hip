@@ -1,0 +1,772 @@
+// engine.hip -- HIP kernels (gfx950) and the C ABI of include/blur_amd.h.
+//
+// Data path of pffft_() (Source.cpp:429-570) on the GPU, per frame:
+//
+//   rowpass_kernel   u8 BGR interleaved (or one f32 plane)  --->  3 float planes, row-major
+//       deinterleave_BGR (Utils.hpp:159-184) + per-row reflect-101 pad (Source.cpp:525-529)
+//       + FFT / pointwise / inverse FFT (:531-533) + crop (:536), two image rows per
+//       complex line, one workgroup per (row pair, channel).
+//   colpass_kernel   3 float planes  --->  u8 BGR interleaved (or one f32 plane)
+//       a workgroup owns a strip of G adjacent columns and reads it straight out of the
+//       row-major planes (the transposes flip_block of :540,562 never materialise), pads
+//       by reflection along the column (:549-551), FFT / pointwise / inverse FFT (:553-555),
+//       crops (:558) and applies interleave_BGR's "+0.5f, truncate" (Utils.hpp:189,204-206),
+//       staging the three channels in LDS so that the strip is written as whole pixels.
+//
+// HBM traffic per pixel: 3 B in + 12 B intermediate out, 12 B intermediate in + 3 B out.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/blur_amd.h"
+#include "fft_engine.hpp"
+#include "host_math.hpp"
+
+using namespace blur_amd;
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr size_t kLdsLimit = 160 * 1024;
+
+// Blocks b and b+8 share an XCD (and its L2).  Give each XCD a contiguous run of work
+// items so that neighbours (which touch the same 128-byte lines) meet in one L2.
+__device__ __forceinline__ int xcd_contiguous(int b, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+// reflect-101 source index of padded position p (Source.cpp:525-529); -1 = trailing zero
+__device__ __forceinline__ int reflect_src(int p, int pad, int len)
+{
+    const int i = p - pad;
+    if (i < 0) return -i;
+    if (i < len) return i;
+    if (i < len + pad) return 2 * (len - 1) - i;
+    return -1;
+}
+
+template <typename T> __device__ __forceinline__ float load_px(const T* p) { return static_cast<float>(*p); }
+
+// ------------------------------------------------------------------------------------
+// row pass: one workgroup = rows (2q, 2q+1) of channel c
+// ------------------------------------------------------------------------------------
+template <typename InT, int CH>
+__global__ __launch_bounds__(kThreads) void rowpass_kernel(const InT* __restrict__ src, float* __restrict__ planes,
+                                                           int rows, int cols, int pad, DevPlan plan,
+                                                           const float2* __restrict__ tw, const float* __restrict__ mperm)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* z = reinterpret_cast<float2*>(smem);
+    const int item = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int pair = item / CH, c = item - pair * CH;
+    const int r0 = 2 * pair;
+    const bool two = r0 + 1 < rows;
+    const int n = plan.n;
+    const InT* row_a = src + (static_cast<size_t>(r0) * cols) * CH + c;
+    const InT* row_b = src + (static_cast<size_t>(r0 + (two ? 1 : 0)) * cols) * CH + c;
+
+    for (int p = threadIdx.x; p < n; p += kThreads) {
+        const int x = reflect_src(p, pad, cols);
+        float2 v = make_float2(0.f, 0.f);
+        if (x >= 0) {
+            v.x = load_px(row_a + static_cast<size_t>(x) * CH);
+            if (two) v.y = load_px(row_b + static_cast<size_t>(x) * CH);
+        }
+        z[phys(p)] = v;
+    }
+    __syncthreads();
+    fftconv_lines<1>(z, 0, plan, tw, mperm);
+
+    float* out_a = planes + (static_cast<size_t>(c) * rows + r0) * cols;
+    float* out_b = out_a + cols;
+    for (int x = threadIdx.x; x < cols; x += kThreads) {
+        const float2 v = z[phys(pad + x)];
+        out_a[x] = v.x;
+        if (two) out_b[x] = v.y;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// column pass: one workgroup = columns [x0, x0 + 2C) of all CH channels
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void store_out(float* p, float v) { *p = v; }
+
+template <typename OutT, int CH, int C>
+__global__ __launch_bounds__(kThreads) void colpass_kernel(const float* __restrict__ planes, OutT* __restrict__ dst,
+                                                           int rows, int cols, int pad, DevPlan plan,
+                                                           const float2* __restrict__ tw, const float* __restrict__ mperm)
+{
+    constexpr int G = 2 * C;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* z = reinterpret_cast<float2*>(smem);
+    const int n = plan.n;
+    const int zs = line_stride(n);
+    uint8_t* stage = reinterpret_cast<uint8_t*>(z + static_cast<size_t>(C) * zs);   // [rows][G][CH] bytes (u8 output only)
+    const int strip = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int x0 = strip * G;
+
+    for (int c = 0; c < CH; ++c) {
+        const float* plane = planes + static_cast<size_t>(c) * rows * cols;
+        // gather the strip: position p of line l  <-  plane[reflect(p)][x0 + 2l, x0 + 2l + 1]
+        for (int idx = threadIdx.x; idx < n * C; idx += kThreads) {
+            const int p = idx / C, l = idx - p * C;
+            const int r = reflect_src(p, pad, rows);
+            float2 v = make_float2(0.f, 0.f);
+            if (r >= 0) {
+                const int col = x0 + 2 * l;
+                const float* s = plane + static_cast<size_t>(r) * cols + col;
+                if (col < cols) v.x = s[0];
+                if (col + 1 < cols) v.y = s[1];
+            }
+            z[l * zs + phys(p)] = v;
+        }
+        __syncthreads();
+        fftconv_lines<C>(z, zs, plan, tw, mperm);
+
+        if constexpr (sizeof(OutT) == 1) {
+            // interleave_BGR<uint8_t,float>: (uint8_t)(value + 0.5f)   Utils.hpp:189,204-206
+            for (int idx = threadIdx.x; idx < rows * C; idx += kThreads) {
+                const int r = idx / C, l = idx - r * C;
+                const float2 v = z[l * zs + phys(pad + r)];
+                uint8_t* s = stage + (static_cast<size_t>(r) * G + 2 * l) * CH + c;
+                s[0] = static_cast<uint8_t>(static_cast<int>(v.x + 0.5f));
+                s[CH] = static_cast<uint8_t>(static_cast<int>(v.y + 0.5f));
+            }
+        } else {
+            for (int idx = threadIdx.x; idx < rows * C; idx += kThreads) {
+                const int r = idx / C, l = idx - r * C;
+                const float2 v = z[l * zs + phys(pad + r)];
+                const int col = x0 + 2 * l;
+                OutT* d = dst + (static_cast<size_t>(r) * cols + col) * CH + c;
+                if (col < cols) d[0] = v.x;
+                if (col + 1 < cols) d[CH] = v.y;
+            }
+        }
+        __syncthreads();
+    }
+
+    if constexpr (sizeof(OutT) == 1) {
+        const int wbytes = (min(G, cols - x0)) * CH;      // valid bytes per row of the strip
+        for (int idx = threadIdx.x; idx < rows * G * CH; idx += kThreads) {
+            const int r = idx / (G * CH), b = idx - r * (G * CH);
+            if (b < wbytes) dst[(static_cast<size_t>(r) * cols + x0) * CH + b] = stage[idx];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// the pieces: flip_block, de/interleave
+// ------------------------------------------------------------------------------------
+// flip_block<float,1>: out[x*h + y] = in[y*w + x]; 64x64 tiles through LDS, both sides coalesced
+__global__ __launch_bounds__(256) void flip_block_kernel(const float* __restrict__ in, float* __restrict__ out, int w, int h)
+{
+    __shared__ float tile[64][65];
+    const int tiles_x = (w + 63) / 64;
+    const int t = blockIdx.x;
+    const int tx = (t % tiles_x) * 64, ty = (t / tiles_x) * 64;
+    const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+    for (int yy = ly; yy < 64; yy += 4) {
+        const int x = tx + lx, y = ty + yy;
+        if (x < w && y < h) tile[yy][lx] = in[static_cast<size_t>(y) * w + x];
+    }
+    __syncthreads();
+    for (int xx = ly; xx < 64; xx += 4) {
+        const int x = tx + xx, y = ty + lx;
+        if (x < w && y < h) out[static_cast<size_t>(x) * h + y] = tile[lx][xx];
+    }
+}
+
+__global__ __launch_bounds__(256) void deinterleave_kernel(const uint8_t* __restrict__ in, float* __restrict__ planes, uint32_t total)
+{
+    for (uint32_t x = blockIdx.x * 256u + threadIdx.x; x < total; x += gridDim.x * 256u) {
+        planes[x] = in[3 * static_cast<size_t>(x)];
+        planes[static_cast<size_t>(total) + x] = in[3 * static_cast<size_t>(x) + 1];
+        planes[2 * static_cast<size_t>(total) + x] = in[3 * static_cast<size_t>(x) + 2];
+    }
+}
+
+__global__ __launch_bounds__(256) void interleave_kernel(const float* __restrict__ planes, uint8_t* __restrict__ out, uint32_t total)
+{
+    for (uint32_t x = blockIdx.x * 256u + threadIdx.x; x < total; x += gridDim.x * 256u) {
+        out[3 * static_cast<size_t>(x)] = static_cast<uint8_t>(static_cast<int>(planes[x] + 0.5f));
+        out[3 * static_cast<size_t>(x) + 1] = static_cast<uint8_t>(static_cast<int>(planes[static_cast<size_t>(total) + x] + 0.5f));
+        out[3 * static_cast<size_t>(x) + 2] = static_cast<uint8_t>(static_cast<int>(planes[2 * static_cast<size_t>(total) + x] + 0.5f));
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// fastboxblur: one sweep of the sliding accumulator along lines of length n.
+// Element (line l, position x, channel c) at buf[l*lstride + x*xstride + c].
+// A wave owns 64 adjacent (line, channel) accumulators; along the line it walks
+// sequentially (the accumulator recurrence), so for the vertical sweep (xstride = row
+// pitch) the 64 lanes read 64 adjacent bytes, and for the horizontal sweep the lines are
+// first brought through LDS in chunks.  V1: direct global accesses, L2 absorbs the reuse.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ int refl101(int i, int n)
+{
+    if (i < 0) i = -i;
+    if (i >= n) i = 2 * (n - 1) - i;
+    return i;
+}
+
+__global__ __launch_bounds__(256) void boxsweep_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int nlines, int n,
+                                                       size_t lstride, size_t xstride, int C, int r, int seg_len)
+{
+    // work item = (segment, line*C + c); segments split long lines so the grid fills the chip
+    const int lc_total = nlines * C;
+    const int nseg = (n + seg_len - 1) / seg_len;
+    const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    if (gid >= static_cast<long long>(lc_total) * nseg) return;
+    const int lc = static_cast<int>(gid % lc_total), seg = static_cast<int>(gid / lc_total);
+    const int l = lc / C, c = lc - l * C;
+    const uint8_t* ip = in + static_cast<size_t>(l) * lstride + c;
+    uint8_t* op = out + static_cast<size_t>(l) * lstride + c;
+    const float iarr = 1.f / static_cast<float>(r + r + 1);
+    const int xs = seg * seg_len, xe = min(n, xs + seg_len);
+    int acc = 0;
+    for (int d = -r; d <= r; ++d) acc += ip[static_cast<size_t>(refl101(xs + d, n)) * xstride];
+    op[static_cast<size_t>(xs) * xstride] = static_cast<uint8_t>(static_cast<int>(static_cast<float>(acc) * iarr + 0.5f));
+    for (int x = xs + 1; x < xe; ++x) {
+        acc += ip[static_cast<size_t>(refl101(x + r, n)) * xstride];
+        acc -= ip[static_cast<size_t>(refl101(x - r - 1, n)) * xstride];
+        op[static_cast<size_t>(x) * xstride] = static_cast<uint8_t>(static_cast<int>(static_cast<float>(acc) * iarr + 0.5f));
+    }
+}
+
+}  // namespace
+
+// ======================================================================================
+// host side: context, caches, launches
+// ======================================================================================
+struct DevicePlan {
+    FftPlan host;
+    DevPlan dev{};
+    float2* d_tw = nullptr;
+};
+
+struct blur_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<int, std::unique_ptr<DevicePlan>> plans;
+    // (n, ksize, quirk, sigma bits) -> device multiplier table in position order
+    std::map<std::tuple<int, int, int, uint64_t>, float*> spectra;
+    float* work = nullptr;       // float planes of one frame
+    size_t work_bytes = 0;
+    uint8_t* box_tmp = nullptr;
+    size_t box_bytes = 0;
+    bool timing = false;
+    std::vector<std::tuple<hipEvent_t, hipEvent_t, int>> ev_busy;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
+    double ms[2] = { 0, 0 };
+    int launches[2] = { 0, 0 };
+};
+
+static thread_local std::string g_create_err;
+
+#define HIP_TRY(ctx, call)                                                                          \
+    do {                                                                                            \
+        hipError_t e_ = (call);                                                                     \
+        if (e_ != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#call) + ": " + hipGetErrorString(e_);                         \
+            return BLUR_ERR_HIP;                                                                    \
+        }                                                                                           \
+    } while (0)
+
+static int fail(blur_ctx* ctx, int code, const char* msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+static int get_plan(blur_ctx* ctx, int n, DevicePlan** out)
+{
+    auto it = ctx->plans.find(n);
+    if (it != ctx->plans.end()) { *out = it->second.get(); return BLUR_OK; }
+    auto dp = std::make_unique<DevicePlan>();
+    if (!make_plan(n, dp->host)) return fail(ctx, BLUR_ERR_UNSUPPORTED, "FFT length is not 2^a 3^b 5^c");
+    dp->dev.n = n;
+    dp->dev.npass = dp->host.npass;
+    for (int i = 0; i < dp->host.npass; ++i) {
+        dp->dev.radix[i] = dp->host.radix[i];
+        dp->dev.m[i] = dp->host.m[i];
+        dp->dev.tw_off[i] = dp->host.tw_off[i];
+    }
+    const size_t bytes = std::max<size_t>(dp->host.tw.size() * sizeof(float), 16);
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dp->d_tw), bytes));
+    if (!dp->host.tw.empty())
+        HIP_TRY(ctx, hipMemcpy(dp->d_tw, dp->host.tw.data(), dp->host.tw.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = dp.get();
+    ctx->plans[n] = std::move(dp);
+    return BLUR_OK;
+}
+
+static int get_spectrum(blur_ctx* ctx, const DevicePlan& plan, double sigma, int ksize, bool quirk, float** out)
+{
+    uint64_t bits;
+    std::memcpy(&bits, &sigma, sizeof bits);
+    const auto key = std::make_tuple(plan.dev.n, ksize, quirk ? 1 : 0, bits);
+    auto it = ctx->spectra.find(key);
+    if (it != ctx->spectra.end()) { *out = it->second; return BLUR_OK; }
+    const int n = plan.dev.n;
+    std::vector<float> m(n / 2 + 1), mp(n);
+    kernel_multipliers(sigma, ksize, n, m.data());
+    permuted_multipliers(plan.host, m.data(), quirk, mp.data());
+    float* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(float) * n));
+    HIP_TRY(ctx, hipMemcpy(d, mp.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    ctx->spectra[key] = d;
+    *out = d;
+    return BLUR_OK;
+}
+
+static int ensure_work(blur_ctx* ctx, size_t bytes)
+{
+    if (ctx->work_bytes >= bytes) return BLUR_OK;
+    if (ctx->work) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->work)); ctx->work = nullptr; ctx->work_bytes = 0; }
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->work), bytes));
+    ctx->work_bytes = bytes;
+    return BLUR_OK;
+}
+
+// ---- event timing -----------------------------------------------------------------
+static int timing_drain(blur_ctx* ctx)
+{
+    for (auto& t : ctx->ev_busy) {
+        hipEvent_t a = std::get<0>(t), b = std::get<1>(t);
+        HIP_TRY(ctx, hipEventSynchronize(b));
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, a, b));
+        ctx->ms[std::get<2>(t)] += ms;
+        ctx->launches[std::get<2>(t)] += 1;
+        ctx->ev_free.emplace_back(a, b);
+    }
+    ctx->ev_busy.clear();
+    return BLUR_OK;
+}
+
+struct TimedLaunch {
+    blur_ctx* ctx; int which; hipEvent_t a = nullptr, b = nullptr; bool on;
+    TimedLaunch(blur_ctx* c, int w) : ctx(c), which(w), on(c->timing)
+    {
+        if (!on) return;
+        if (ctx->ev_busy.size() >= 8192) timing_drain(ctx);
+        if (ctx->ev_free.empty()) {
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { on = false; return; }
+        } else { a = ctx->ev_free.back().first; b = ctx->ev_free.back().second; ctx->ev_free.pop_back(); }
+        (void)hipEventRecord(a, ctx->stream);
+    }
+    ~TimedLaunch()
+    {
+        if (!on) return;
+        (void)hipEventRecord(b, ctx->stream);
+        ctx->ev_busy.emplace_back(a, b, which);
+    }
+};
+
+// ---- launches ---------------------------------------------------------------------
+static size_t row_lds_bytes(int n) { return static_cast<size_t>(line_stride(n)) * sizeof(float2); }
+static size_t col_lds_bytes(int n, int C, int rows, int out_bytes_per_px)
+{
+    return static_cast<size_t>(C) * line_stride(n) * sizeof(float2) + (out_bytes_per_px ? static_cast<size_t>(rows) * 2 * C * out_bytes_per_px : 0) + 16;
+}
+
+template <typename K> static int set_lds(blur_ctx* ctx, K kernel, size_t bytes)
+{
+    if (bytes > 64 * 1024)
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(bytes)));
+    return BLUR_OK;
+}
+
+template <typename InT, int CH>
+static int launch_rowpass(blur_ctx* ctx, const InT* src, float* planes, int rows, int cols, int pad,
+                          const DevicePlan& plan, const float* mperm)
+{
+    const size_t lds = row_lds_bytes(plan.dev.n);
+    if (lds > kLdsLimit) return fail(ctx, BLUR_ERR_UNSUPPORTED, "row FFT length exceeds LDS capacity");
+    if (int rc = set_lds(ctx, rowpass_kernel<InT, CH>, lds)) return rc;
+    const int grid = ((rows + 1) / 2) * CH;
+    TimedLaunch t(ctx, 0);
+    hipLaunchKernelGGL((rowpass_kernel<InT, CH>), dim3(grid), dim3(kThreads), lds, ctx->stream,
+                       src, planes, rows, cols, pad, plan.dev, plan.d_tw, mperm);
+    HIP_TRY(ctx, hipGetLastError());
+    return BLUR_OK;
+}
+
+template <typename OutT, int CH, int C>
+static int launch_colpass_c(blur_ctx* ctx, const float* planes, OutT* dst, int rows, int cols, int pad,
+                            const DevicePlan& plan, const float* mperm)
+{
+    const size_t lds = col_lds_bytes(plan.dev.n, C, rows, sizeof(OutT) == 1 ? CH : 0);
+    if (int rc = set_lds(ctx, colpass_kernel<OutT, CH, C>, lds)) return rc;
+    const int grid = (cols + 2 * C - 1) / (2 * C);
+    TimedLaunch t(ctx, 1);
+    hipLaunchKernelGGL((colpass_kernel<OutT, CH, C>), dim3(grid), dim3(kThreads), lds, ctx->stream,
+                       planes, dst, rows, cols, pad, plan.dev, plan.d_tw, mperm);
+    HIP_TRY(ctx, hipGetLastError());
+    return BLUR_OK;
+}
+
+template <typename OutT, int CH>
+static int launch_colpass(blur_ctx* ctx, const float* planes, OutT* dst, int rows, int cols, int pad,
+                          const DevicePlan& plan, const float* mperm, int col_group)
+{
+    const int obpp = sizeof(OutT) == 1 ? CH : 0;
+    int C = col_group > 0 ? col_group / 2 : 4;
+    if (C >= 8) C = 8; else if (C >= 4) C = 4; else if (C >= 2) C = 2; else C = 1;
+    while (C > 1 && col_lds_bytes(plan.dev.n, C, rows, obpp) > kLdsLimit) C /= 2;
+    if (col_lds_bytes(plan.dev.n, C, rows, obpp) > kLdsLimit)
+        return fail(ctx, BLUR_ERR_UNSUPPORTED, "column FFT length exceeds LDS capacity");
+    switch (C) {
+    case 8: return launch_colpass_c<OutT, CH, 8>(ctx, planes, dst, rows, cols, pad, plan, mperm);
+    case 4: return launch_colpass_c<OutT, CH, 4>(ctx, planes, dst, rows, cols, pad, plan, mperm);
+    case 2: return launch_colpass_c<OutT, CH, 2>(ctx, planes, dst, rows, cols, pad, plan, mperm);
+    default: return launch_colpass_c<OutT, CH, 1>(ctx, planes, dst, rows, cols, pad, plan, mperm);
+    }
+}
+
+struct Prepared {
+    Sizing sz;
+    DevicePlan *row = nullptr, *col = nullptr;
+    float *m_row = nullptr, *m_col = nullptr;
+    int col_group = 0;
+};
+
+static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (rows <= 0 || cols <= 0 || !(sigma > 0)) return fail(ctx, BLUR_ERR_INVALID, "rows, cols and sigma must be positive");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    p.sz = pffft_sizing(rows, cols, sigma);
+    if (p.sz.pad > rows - 1 || p.sz.pad > cols - 1)
+        return fail(ctx, BLUR_ERR_UNSUPPORTED, "pad > min(rows, cols) - 1: reflect-101 would read outside the image (README.md:33-38)");
+    const bool quirk = opts ? opts->nyquist_quirk != 0 : true;
+    p.col_group = opts ? opts->col_group : 0;
+    if (int rc = get_plan(ctx, p.sz.n_row, &p.row)) return rc;
+    if (int rc = get_plan(ctx, p.sz.n_col, &p.col)) return rc;
+    if (int rc = get_spectrum(ctx, *p.row, sigma, p.sz.kSize, quirk, &p.m_row)) return rc;
+    if (int rc = get_spectrum(ctx, *p.col, sigma, p.sz.kSize, quirk, &p.m_col)) return rc;
+    return BLUR_OK;
+}
+
+// ======================================================================================
+// C ABI
+// ======================================================================================
+extern "C" {
+
+void blur_opts_default(blur_opts* o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof *o);
+    o->nyquist_quirk = 1;
+}
+
+int blur_gaussian_window(double sigma, int max_width) { return gaussian_window(sigma, max_width); }
+
+int blur_get_gaussian(float* kernel, double sigma, int width, int fft_length)
+{
+    if (!kernel || !(sigma > 0) || width < 0 || fft_length < 0) return BLUR_ERR_INVALID;
+    get_gaussian(kernel, sigma, width, fft_length);
+    return BLUR_OK;
+}
+
+int blur_is_valid_size(int n) { return is_valid_size(n); }
+int blur_nearest_transform_size(int n) { return nearest_transform_size(n); }
+
+int blur_pffft_sizing(int rows, int cols, double sigma, int out[6])
+{
+    if (!out || rows <= 0 || cols <= 0 || !(sigma > 0)) return BLUR_ERR_INVALID;
+    const Sizing s = pffft_sizing(rows, cols, sigma);
+    out[0] = s.kSize; out[1] = s.pad; out[2] = s.n_col; out[3] = s.n_row; out[4] = s.tz_col; out[5] = s.tz_row;
+    return BLUR_OK;
+}
+
+int blur_kernel_multipliers(double sigma, int ksize, int n, float* m)
+{
+    if (!m || !(sigma > 0) || ksize <= 0 || n < ksize) return BLUR_ERR_INVALID;
+    kernel_multipliers(sigma, ksize, n, m);
+    return BLUR_OK;
+}
+
+int blur_fft_plan_radices(int n, int* radices)
+{
+    FftPlan p;
+    if (!radices || !make_plan(n, p)) return 0;
+    for (int i = 0; i < p.npass; ++i) radices[i] = p.radix[i];
+    return p.npass;
+}
+
+int blur_ctx_create(blur_ctx** out, int device)
+{
+    if (!out) return BLUR_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0) {
+        g_create_err = std::string("no HIP device available: ") + (e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return BLUR_ERR_HIP;
+    }
+    if (device < 0 || device >= count) { g_create_err = "device ordinal out of range"; return BLUR_ERR_INVALID; }
+    e = hipSetDevice(device);
+    if (e != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
+    blur_ctx* c = new blur_ctx();
+    c->device = device;
+    *out = c;
+    return BLUR_OK;
+}
+
+int blur_ctx_destroy(blur_ctx* ctx)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->plans) if (kv.second->d_tw) (void)hipFree(kv.second->d_tw);
+    for (auto& kv : ctx->spectra) (void)hipFree(kv.second);
+    if (ctx->work) (void)hipFree(ctx->work);
+    if (ctx->box_tmp) (void)hipFree(ctx->box_tmp);
+    for (auto& t : ctx->ev_busy) { (void)hipEventDestroy(std::get<0>(t)); (void)hipEventDestroy(std::get<1>(t)); }
+    for (auto& t : ctx->ev_free) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
+    delete ctx;
+    return BLUR_OK;
+}
+
+int blur_ctx_set_stream(blur_ctx* ctx, void* hip_stream)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    return BLUR_OK;
+}
+
+int blur_ctx_synchronize(blur_ctx* ctx)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BLUR_OK;
+}
+
+const char* blur_last_error(const blur_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int blur_ctx_timing_enable(blur_ctx* ctx, int on)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    ctx->timing = on != 0;
+    return BLUR_OK;
+}
+
+int blur_ctx_timing(blur_ctx* ctx, double out_ms[2], int out_launches[2], int reset)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (int rc = timing_drain(ctx)) return rc;
+    for (int i = 0; i < 2; ++i) {
+        if (out_ms) out_ms[i] = ctx->ms[i];
+        if (out_launches) out_launches[i] = ctx->launches[i];
+        if (reset) { ctx->ms[i] = 0; ctx->launches[i] = 0; }
+    }
+    return BLUR_OK;
+}
+
+int blur_gaussian_u8c3_batch_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes,
+                                 int rows, int cols, double sigma, const blur_opts* opts)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!d_src || !d_dst || nframes < 0) return fail(ctx, BLUR_ERR_INVALID, "null frame pointer or negative frame count");
+    Prepared p;
+    if (int rc = prepare(ctx, rows, cols, sigma, opts, p)) return rc;
+    const size_t px = static_cast<size_t>(rows) * cols;
+    if (int rc = ensure_work(ctx, px * 3 * sizeof(float))) return rc;
+    // frame by frame: the 12 B/px float intermediate of one frame stays in the 256 MiB
+    // Infinity Cache between the two kernels
+    for (int f = 0; f < nframes; ++f) {
+        const uint8_t* s = d_src + static_cast<size_t>(f) * px * 3;
+        uint8_t* d = d_dst + static_cast<size_t>(f) * px * 3;
+        if (int rc = launch_rowpass<uint8_t, 3>(ctx, s, ctx->work, rows, cols, p.sz.pad, *p.row, p.m_row)) return rc;
+        if (int rc = launch_colpass<uint8_t, 3>(ctx, ctx->work, d, rows, cols, p.sz.pad, *p.col, p.m_col, p.col_group)) return rc;
+    }
+    return BLUR_OK;
+}
+
+int blur_gaussian_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int rows, int cols, double sigma, const blur_opts* opts)
+{
+    return blur_gaussian_u8c3_batch_dev(ctx, d_src, d_dst, 1, rows, cols, sigma, opts);
+}
+
+int blur_gaussian_f32c1_dev(blur_ctx* ctx, const float* d_src, float* d_dst, int rows, int cols, double sigma, const blur_opts* opts)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!d_src || !d_dst) return fail(ctx, BLUR_ERR_INVALID, "null plane pointer");
+    Prepared p;
+    if (int rc = prepare(ctx, rows, cols, sigma, opts, p)) return rc;
+    const size_t px = static_cast<size_t>(rows) * cols;
+    if (int rc = ensure_work(ctx, px * sizeof(float))) return rc;
+    if (int rc = launch_rowpass<float, 1>(ctx, d_src, ctx->work, rows, cols, p.sz.pad, *p.row, p.m_row)) return rc;
+    return launch_colpass<float, 1>(ctx, ctx->work, d_dst, rows, cols, p.sz.pad, *p.col, p.m_col, p.col_group);
+}
+
+int blur_rowpass_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, float* d_planes, int rows, int cols, double sigma, const blur_opts* opts)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!d_src || !d_planes) return fail(ctx, BLUR_ERR_INVALID, "null pointer");
+    Prepared p;
+    if (int rc = prepare(ctx, rows, cols, sigma, opts, p)) return rc;
+    return launch_rowpass<uint8_t, 3>(ctx, d_src, d_planes, rows, cols, p.sz.pad, *p.row, p.m_row);
+}
+
+int blur_gaussian_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int rows, int cols, double sigma, const blur_opts* opts)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!src || !dst || rows <= 0 || cols <= 0) return fail(ctx, BLUR_ERR_INVALID, "null image or non-positive size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = static_cast<size_t>(rows) * cols * 3;
+    uint8_t* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    int rc = BLUR_OK;
+    hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) rc = blur_gaussian_u8c3_dev(ctx, d, d, rows, cols, sigma, opts);
+    if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { ctx->err = std::string("host blur: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
+    return rc;
+}
+
+int blur_gaussian_f32c1_host(blur_ctx* ctx, const float* src, float* dst, int rows, int cols, double sigma, const blur_opts* opts)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!src || !dst || rows <= 0 || cols <= 0) return fail(ctx, BLUR_ERR_INVALID, "null plane or non-positive size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = static_cast<size_t>(rows) * cols * sizeof(float);
+    float* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), 2 * bytes));
+    int rc = BLUR_OK;
+    hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) rc = blur_gaussian_f32c1_dev(ctx, d, d + static_cast<size_t>(rows) * cols, rows, cols, sigma, opts);
+    if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpyAsync(dst, d + static_cast<size_t>(rows) * cols, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { ctx->err = std::string("host blur: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
+    return rc;
+}
+
+int blur_flip_block_f32_dev(blur_ctx* ctx, const float* d_in, float* d_out, int w, int h)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!d_in || !d_out || w <= 0 || h <= 0 || d_in == d_out) return fail(ctx, BLUR_ERR_INVALID, "flip_block: bad arguments (out of place only)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int tiles = ((w + 63) / 64) * ((h + 63) / 64);
+    hipLaunchKernelGGL(flip_block_kernel, dim3(tiles), dim3(256), 0, ctx->stream, d_in, d_out, w, h);
+    HIP_TRY(ctx, hipGetLastError());
+    return BLUR_OK;
+}
+
+int blur_deinterleave_bgr_u8_f32_dev(blur_ctx* ctx, const uint8_t* d_in, float* d_planes, uint32_t total)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!d_in || !d_planes) return fail(ctx, BLUR_ERR_INVALID, "null pointer");
+    if (!total) return BLUR_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const unsigned grid = std::min<uint32_t>((total + 255) / 256, 2048u * 8);
+    hipLaunchKernelGGL(deinterleave_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_in, d_planes, total);
+    HIP_TRY(ctx, hipGetLastError());
+    return BLUR_OK;
+}
+
+int blur_interleave_bgr_f32_u8_dev(blur_ctx* ctx, const float* d_planes, uint8_t* d_out, uint32_t total)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!d_planes || !d_out) return fail(ctx, BLUR_ERR_INVALID, "null pointer");
+    if (!total) return BLUR_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const unsigned grid = std::min<uint32_t>((total + 255) / 256, 2048u * 8);
+    hipLaunchKernelGGL(interleave_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_planes, d_out, total);
+    HIP_TRY(ctx, hipGetLastError());
+    return BLUR_OK;
+}
+
+int blur_fastboxblur_u8_dev(blur_ctx* ctx, uint8_t* d_inout, int w, int h, int channels, int ksize, int passes)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!d_inout || w <= 0 || h <= 0 || channels <= 0 || ksize <= 0 || passes < 0)
+        return fail(ctx, BLUR_ERR_INVALID, "fastboxblur: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = static_cast<size_t>(w) * h * channels;
+    if (ctx->box_bytes < bytes) {
+        if (ctx->box_tmp) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->box_tmp)); ctx->box_tmp = nullptr; ctx->box_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->box_tmp), bytes));
+        ctx->box_bytes = bytes;
+    }
+    uint8_t *a = d_inout, *b = ctx->box_tmp;
+    auto sweep = [&](int nlines, int n, size_t lstride, size_t xstride) {
+        int r = (ksize - 1) / 2;
+        if (r > n - 1) r = n - 1;
+        const int seg_len = std::max(64, (n + 31) / 32);
+        const int nseg = (n + seg_len - 1) / seg_len;
+        const long long items = static_cast<long long>(nlines) * channels * nseg;
+        const unsigned grid = static_cast<unsigned>((items + 255) / 256);
+        hipLaunchKernelGGL(boxsweep_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, b, nlines, n, lstride, xstride, channels, r, seg_len);
+        std::swap(a, b);
+    };
+    for (int p = 0; p < passes; ++p) sweep(h, w, static_cast<size_t>(w) * channels, static_cast<size_t>(channels));
+    for (int p = 0; p < passes; ++p) sweep(w, h, static_cast<size_t>(channels), static_cast<size_t>(w) * channels);
+    HIP_TRY(ctx, hipGetLastError());
+    if (a != d_inout) HIP_TRY(ctx, hipMemcpyAsync(d_inout, a, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return BLUR_OK;
+}
+
+int blur_fastboxblur_u8_host(blur_ctx* ctx, uint8_t* inout, int w, int h, int channels, int ksize, int passes)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!inout || w <= 0 || h <= 0 || channels <= 0) return fail(ctx, BLUR_ERR_INVALID, "fastboxblur: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = static_cast<size_t>(w) * h * channels;
+    uint8_t* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    int rc = BLUR_OK;
+    hipError_t e = hipMemcpyAsync(d, inout, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) rc = blur_fastboxblur_u8_dev(ctx, d, w, h, channels, ksize, passes);
+    if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpyAsync(inout, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { ctx->err = std::string("host fastboxblur: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
+    return rc;
+}
+
+int blur_malloc(blur_ctx* ctx, void** d_ptr, size_t bytes)
+{
+    if (!ctx || !d_ptr) return BLUR_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return BLUR_OK;
+}
+
+int blur_free(blur_ctx* ctx, void* d_ptr)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    HIP_TRY(ctx, hipFree(d_ptr));
+    return BLUR_OK;
+}
+
+int blur_memcpy_h2d(blur_ctx* ctx, void* d_dst, const void* src, size_t bytes)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    HIP_TRY(ctx, hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BLUR_OK;
+}
+
+int blur_memcpy_d2h(blur_ctx* ctx, void* dst, const void* d_src, size_t bytes)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BLUR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// host_math.cpp -- see host_math.hpp.  Written from the reference's semantics
+// (Source.cpp:60-102,434-457; Utils.hpp:141-157), not from its text.
+#include "host_math.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+namespace blur_amd {
+
+int gaussian_window(double sigma, int max_width)
+{
+    // the reference narrows the double expression to float, then works in float and
+    // truncates (Source.cpp:64-65); an even width is bumped to the next odd one (:68)
+    const float radius = static_cast<float>(sigma * std::sqrt(2 * std::log(255)) - 1);
+    int width = static_cast<int>(radius * 2 + .5f);
+    if (max_width) width = std::min(width, max_width);
+    return width | 1;
+}
+
+void get_gaussian(float* kernel, double sigma, int width, int fft_length)
+{
+    if (!width) width = gaussian_window(sigma);
+    const int len = fft_length ? fft_length : width;
+    const double two_s2 = 2. * sigma * sigma;
+    const double norm = 3.14159265358979323846 * two_s2;
+    const float half = (width - 1) / 2.f;
+    std::vector<float> taps(width);
+    // tap t sits at offset y = t - half (a float, as the reference's loop counter is,
+    // Source.cpp:88); y*y is a float product, everything after it double, and each tap
+    // is rounded to float BEFORE the normalisation (Source.cpp:89-93)
+    for (int t = 0; t < width; ++t) {
+        const float y = -half + static_cast<float>(t);
+        taps[t] = static_cast<float>(std::exp(-(y * y) / two_s2) / norm);
+    }
+    double total = 0.;
+    for (float v : taps) total += v;
+    const double inv = 1. / total;
+    for (float& v : taps) v = static_cast<float>(v * inv);
+    if (!fft_length) {
+        std::copy(taps.begin(), taps.end(), kernel);
+        return;
+    }
+    // zero-extend to the FFT length with the centre tap at index 0 (Source.cpp:96-100)
+    std::fill(kernel, kernel + len, 0.f);
+    const int c = width / 2;
+    for (int t = 0; t < width; ++t) kernel[(t - c + len) % len] = taps[t];
+}
+
+int is_valid_size(int n)
+{
+    // n = 32 * 2^a 3^b 5^c, where a factor is only stripped while the rest stays >= 32
+    for (int p : { 5, 3, 2 })
+        while (n >= p * 32 && n % p == 0) n /= p;
+    return n == 32;
+}
+
+int nearest_transform_size(int n)
+{
+    n = std::max(n, 32);
+    n = (n + 31) / 32 * 32;
+    while (!is_valid_size(n)) n += 32;
+    return n;
+}
+
+Sizing pffft_sizing(int rows, int cols, double sigma)
+{
+    Sizing s{};
+    s.kSize = gaussian_window(sigma, std::max(rows, cols));
+    s.pad = (s.kSize - 1) / 2;
+    auto fit = [](int want, int& tz) {
+        if (is_valid_size(want)) { tz = 0; return want; }
+        const int n = nearest_transform_size(want);
+        tz = n - want;
+        return n;
+    };
+    s.n_col = fit(rows + 2 * s.pad, s.tz_col);
+    s.n_row = fit(cols + 2 * s.pad, s.tz_row);
+    return s;
+}
+
+void kernel_multipliers(double sigma, int ksize, int n, float* m)
+{
+    std::vector<float> k(std::max(n, ksize));
+    get_gaussian(k.data(), sigma, ksize, n);
+    const int pad = ksize / 2;
+    const float scaler = 1.f / n;
+    const long double two_pi = 6.283185307179586476925286766559L;
+    for (int b = 0; b <= n / 2; ++b) {
+        // the rotated kernel is even, so its DFT is the cosine sum (README.md:129)
+        long double acc = k[0];
+        for (int t = 1; t <= pad; ++t) {
+            const long long ph = (static_cast<long long>(b) * t) % n;
+            acc += (static_cast<long double>(k[t]) + static_cast<long double>(k[n - t])) *
+                   cosl(two_pi * static_cast<long double>(ph) / n);
+        }
+        m[b] = static_cast<float>(acc) * scaler;
+    }
+}
+
+static void choose_radices(int n, std::vector<int>& out)
+{
+    // Few LDS round trips matter more than flops: take the largest radix first.
+    // Supported butterflies: 16 10 9 8 6 5 4 3 2.
+    int c2 = 0, c3 = 0, c5 = 0, r = n;
+    while (r % 2 == 0) { r /= 2; ++c2; }
+    while (r % 3 == 0) { r /= 3; ++c3; }
+    while (r % 5 == 0) { r /= 5; ++c5; }
+    out.clear();
+    if (r != 1) return;
+    // pair 5s with 2s into radix 10, 3s with 2s into radix 6, 3s together into 9
+    while (c5 > 0 && c2 > 0 && c2 % 4 != 0) { out.push_back(10); --c5; --c2; }
+    while (c5 > 0) { out.push_back(5); --c5; }
+    while (c3 >= 2) { out.push_back(9); c3 -= 2; }
+    while (c3 > 0 && c2 > 0 && c2 % 4 != 0) { out.push_back(6); --c3; --c2; }
+    while (c3 > 0) { out.push_back(3); --c3; }
+    while (c2 >= 4) { out.push_back(16); c2 -= 4; }
+    if (c2 == 3) out.push_back(8);
+    if (c2 == 2) out.push_back(4);
+    if (c2 == 1) out.push_back(2);
+    // large radices first (their passes carry the most twiddles per butterfly and the
+    // last pass is fused with the multiply and the first inverse pass)
+    std::sort(out.begin(), out.end(), std::greater<int>());
+}
+
+bool make_plan(int n, FftPlan& p)
+{
+    std::vector<int> rad;
+    choose_radices(n, rad);
+    if (n < 2 || rad.empty() || static_cast<int>(rad.size()) > kMaxPasses) return false;
+    p = FftPlan{};
+    p.n = n;
+    p.npass = static_cast<int>(rad.size());
+    const long double two_pi = 6.283185307179586476925286766559L;
+    int len = n, off = 0;
+    for (int i = 0; i < p.npass; ++i) {
+        const int R = rad[i], m = len / R;
+        p.radix[i] = R;
+        p.m[i] = m;
+        p.tw_off[i] = off;
+        if (m > 1) {
+            p.tw.resize(static_cast<size_t>(off + (R - 1) * m) * 2);
+            for (int q = 1; q < R; ++q)
+                for (int j = 0; j < m; ++j) {
+                    const long double a = -two_pi * static_cast<long double>((static_cast<long long>(j) * q) % len) / len;
+                    const size_t e = static_cast<size_t>(off + (q - 1) * m + j) * 2;
+                    p.tw[e] = static_cast<float>(cosl(a));
+                    p.tw[e + 1] = static_cast<float>(sinl(a));
+                }
+            off += (R - 1) * m;
+        }
+        len = m;
+    }
+    p.freq_of_pos.resize(n);
+    for (int pos = 0; pos < n; ++pos) {
+        int rem = pos, f = 0, w = 1;
+        for (int i = 0; i < p.npass; ++i) {
+            const int q = rem / p.m[i];
+            rem -= q * p.m[i];
+            f += q * w;
+            w *= p.radix[i];
+        }
+        p.freq_of_pos[pos] = f;
+    }
+    return true;
+}
+
+void permuted_multipliers(const FftPlan& plan, const float* m, bool quirk, float* mperm)
+{
+    const int n = plan.n;
+    for (int pos = 0; pos < n; ++pos) {
+        int f = plan.freq_of_pos[pos];
+        if (f > n / 2) f = n - f;
+        if (quirk && f == n / 2) f = 0;
+        mperm[pos] = m[f];
+    }
+}
+
+}  // namespace blur_amd

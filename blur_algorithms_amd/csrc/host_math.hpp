@@ -1,0 +1,54 @@
+// host_math.hpp -- host-side arithmetic of the engine: the reference's sizing and
+// kernel generation (bit-identical), the kernel-spectrum multipliers and the FFT plans.
+// No HIP in here; compiled into libblur_amd.so and usable from plain C++.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace blur_amd {
+
+// Source.cpp:60-73
+int gaussian_window(double sigma, int max_width = 0);
+// Source.cpp:75-102 (kernel: max(width, fft_length) floats)
+void get_gaussian(float* kernel, double sigma, int width, int fft_length);
+// Utils.hpp:141-157
+int is_valid_size(int n);
+int nearest_transform_size(int n);
+
+struct Sizing {
+    int kSize, pad;
+    int n_col;   // sizes[0]: FFT length of the column pass (rows + 2 pad, rounded up)
+    int n_row;   // sizes[1]: FFT length of the row pass
+    int tz_col, tz_row;
+};
+// Source.cpp:434-457
+Sizing pffft_sizing(int rows, int cols, double sigma);
+
+// m[b] = float(Re DFT(kernel)[b]) * (1.f / n), b = 0..n/2   (Source.cpp:423,506-507)
+void kernel_multipliers(double sigma, int ksize, int n, float* m);
+
+// ---- FFT plan: in-place decimation-in-frequency forward, decimation-in-time inverse.
+// Forward pass i works on blocks of length len[i] = N / (radix[0]*...*radix[i-1]) with
+// m[i] = len[i] / radix[i]; after all passes frequency f sits at position pos with
+//   pos = q0*m[0] + q1*m[1] + ... , f = q0 + radix[0]*(q1 + radix[1]*(q2 + ...)).
+// The inverse runs the same passes backwards, so no reordering is ever done: the
+// pointwise multiply uses a multiplier table permuted to position order.
+constexpr int kMaxPasses = 8;
+struct FftPlan {
+    int n = 0;
+    int npass = 0;
+    int radix[kMaxPasses] = {};
+    int m[kMaxPasses] = {};
+    int tw_off[kMaxPasses] = {};      // offset (in complex elements) of pass i's twiddles
+    std::vector<float> tw;            // interleaved re,im; pass i: tw[(q-1)*m + j] = exp(-2 pi i j q / len_i)
+    std::vector<int> freq_of_pos;     // n entries
+};
+// returns false if n has a prime factor other than 2, 3, 5
+bool make_plan(int n, FftPlan& plan);
+
+// multiplier table in POSITION order for a complex FFT of length n:
+// mperm[pos] = m[min(f, n-f)], f = freq_of_pos[pos]; with `quirk`, f == n/2 uses m[0]
+// (Source.cpp:420-425, the imaginary slot of i = 0 holds the Nyquist bin).
+void permuted_multipliers(const FftPlan& plan, const float* m, bool quirk, float* mperm);
+
+}  // namespace blur_amd

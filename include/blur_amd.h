@@ -1,0 +1,154 @@
+/*
+ * blur_amd.h -- C ABI of the MI355X (gfx950) FFT Gaussian-blur engine.
+ *
+ * This is the drop-in boundary for ONE hot path of michelerenzullo/Blur_algorithms:
+ * the 1D-tiled FFT convolution `pffft_(cv::Mat&, double)` (Source.cpp:429-570) and,
+ * for BASELINE config 5, `fastboxblur` (call site Source.cpp:587).  The reference has
+ * no FFI of its own (README.md:151-152 "Usage and APIs coming soon"); the entry points
+ * below are what a binding for that path would bind: plain pointers and sizes, no C++
+ * or torch types.  Each one cites the reference interface it replaces.
+ *
+ * All device work is hand-written HIP for gfx950 inside libblur_amd.so; there is no
+ * CPU fallback: a call that cannot run on the GPU returns an error code.
+ *
+ * Threading: a blur_ctx is thread-compatible (one call at a time per ctx).  Calls on
+ * device pointers are ASYNCHRONOUS on the ctx's stream unless stated otherwise.
+ */
+#ifndef BLUR_AMD_H
+#define BLUR_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BLUR_AMD_VERSION 100
+
+/* status codes (the reference returns void and checks nothing: Utils.hpp:59-65,
+   Source.cpp:477-478,612-621) */
+enum {
+    BLUR_OK = 0,
+    BLUR_ERR_INVALID = 1,      /* bad argument (null pointer, non-positive size, sigma <= 0) */
+    BLUR_ERR_UNSUPPORTED = 2,  /* pad > min(rows,cols)-1 (UB in the reference, README.md:33-38) or FFT length too long for LDS */
+    BLUR_ERR_HIP = 3,          /* a HIP runtime call failed; see blur_last_error() */
+    BLUR_ERR_NOMEM = 4
+};
+
+typedef struct blur_ctx blur_ctx;
+
+/* Options of the whole-image blur.  Zero-initialise, then blur_opts_default(). */
+typedef struct blur_opts {
+    /* 1 (default): reproduce pffft_sorted_optimized_convolution exactly
+       (Source.cpp:420-425): the Nyquist bin, packed in slot 1 of pffft's ordered
+       layout, is scaled with the kernel's DC gain.  0: scale it with the kernel's
+       Nyquist gain (what pocketfft_1D does, Source.cpp:362,378). */
+    int nyquist_quirk;
+    /* columns per workgroup of the column pass (0 = auto: 8 or less as LDS allows) */
+    int col_group;
+    int reserved[6];
+} blur_opts;
+
+void blur_opts_default(blur_opts* o);
+
+/* ---- host-side sizing: bit-identical replacements, no GPU needed ------------------ */
+
+/* gaussian_window(sigma, max_width)                      Source.cpp:60-73 */
+int blur_gaussian_window(double sigma, int max_width);
+
+/* getGaussian(kernel, sigma, width, FFT_length)          Source.cpp:75-102
+   kernel must hold max(width, fft_length) floats (width==0 -> gaussian_window(sigma)). */
+int blur_get_gaussian(float* kernel, double sigma, int width, int fft_length);
+
+/* isValidSize / nearestTransformSize                     Utils.hpp:141-157 */
+int blur_is_valid_size(int n);
+int blur_nearest_transform_size(int n);
+
+/* the sizing block of pffft_()                           Source.cpp:434-457
+   out = { kSize, pad, sizes[0] (column FFT length), sizes[1] (row FFT length),
+           trailing_zeros[0], trailing_zeros[1] } */
+int blur_pffft_sizing(int rows, int cols, double sigma, int out[6]);
+
+/* per-bin multiplier kerf[2i]*scaler of Source.cpp:423 for bins 0..n/2 (n/2+1 floats);
+   the kernel spectrum is computed on the host in float64 and rounded to float once */
+int blur_kernel_multipliers(double sigma, int ksize, int n, float* m);
+
+/* radix sequence the engine uses for a complex FFT of length n (returns the number of
+   passes, 0 if n is unsupported); radices[] must hold 16 ints */
+int blur_fft_plan_radices(int n, int* radices);
+
+/* ---- context ---------------------------------------------------------------------- */
+
+/* device: HIP device ordinal.  Owns plan/twiddle caches, kernel-spectrum caches and the
+   float32 intermediate workspace.  (Role of pffft_new_setup/pffft_destroy_setup,
+   Source.cpp:477-478,565-566, which the reference rebuilds on every call.) */
+int blur_ctx_create(blur_ctx** out, int device);
+int blur_ctx_destroy(blur_ctx* ctx);
+/* hipStream_t to launch on (NULL = the default stream) */
+int blur_ctx_set_stream(blur_ctx* ctx, void* hip_stream);
+int blur_ctx_synchronize(blur_ctx* ctx);
+/* message of the last failing call on this ctx ("" if none); ctx may be NULL for
+   failures of blur_ctx_create */
+const char* blur_last_error(const blur_ctx* ctx);
+
+/* Per-kernel timing with HIP events on the ctx's stream.  While enabled, every launch
+   of the row-pass and column-pass kernels is bracketed by events; blur_ctx_timing()
+   synchronises, then returns the summed milliseconds and launch counts since the last
+   reset:  out_ms[0]=row pass, out_ms[1]=column pass; out_launches likewise. */
+int blur_ctx_timing_enable(blur_ctx* ctx, int on);
+int blur_ctx_timing(blur_ctx* ctx, double out_ms[2], int out_launches[2], int reset);
+
+/* ---- the hot path: pffft_(image, sigma)             Source.cpp:429-570 ------------- */
+
+/* One BGR/RGB u8 frame, interleaved, rows*cols*3 bytes contiguous (cv::Mat::data of
+   Source.cpp:459-461,567), DEVICE pointers.  dst may equal src (the reference works in
+   place).  Asynchronous on the ctx's stream. */
+int blur_gaussian_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst,
+                           int rows, int cols, double sigma, const blur_opts* opts);
+
+/* nframes frames of identical shape stored back to back (frame stride rows*cols*3). */
+int blur_gaussian_u8c3_batch_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes,
+                                 int rows, int cols, double sigma, const blur_opts* opts);
+
+/* One float32 plane (the per-channel body Source.cpp:510-564; BASELINE config 1). */
+int blur_gaussian_f32c1_dev(blur_ctx* ctx, const float* d_src, float* d_dst,
+                            int rows, int cols, double sigma, const blur_opts* opts);
+
+/* HOST pointers: copy in, blur, copy out, synchronise (what a cv::Mat caller needs). */
+int blur_gaussian_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst,
+                            int rows, int cols, double sigma, const blur_opts* opts);
+int blur_gaussian_f32c1_host(blur_ctx* ctx, const float* src, float* dst,
+                             int rows, int cols, double sigma, const blur_opts* opts);
+
+/* Row pass only (Source.cpp:520-537): u8c3 frame -> three float planes, row-major
+   (what `resf` holds at Source.cpp:536).  d_planes: 3*rows*cols floats.  For tests. */
+int blur_rowpass_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, float* d_planes,
+                          int rows, int cols, double sigma, const blur_opts* opts);
+
+/* ---- the pieces either side of it -------------------------------------------------- */
+
+/* flip_block<float,1>(in, out, w, h): out[x*h+y] = in[y*w+x]     call sites Source.cpp:540,562 */
+int blur_flip_block_f32_dev(blur_ctx* ctx, const float* d_in, float* d_out, int w, int h);
+
+/* deinterleave_BGR<uint8_t,float> / interleave_BGR<uint8_t,float>   Utils.hpp:159-210
+   d_planes: 3 planes of `total` floats, back to back. */
+int blur_deinterleave_bgr_u8_f32_dev(blur_ctx* ctx, const uint8_t* d_in, float* d_planes, uint32_t total);
+int blur_interleave_bgr_f32_u8_dev(blur_ctx* ctx, const float* d_planes, uint8_t* d_out, uint32_t total);
+
+/* fastboxblur(in, w, h, channels, ksize, passes), in place     call site Source.cpp:587 */
+int blur_fastboxblur_u8_dev(blur_ctx* ctx, uint8_t* d_inout, int w, int h, int channels,
+                            int ksize, int passes);
+int blur_fastboxblur_u8_host(blur_ctx* ctx, uint8_t* inout, int w, int h, int channels,
+                             int ksize, int passes);
+
+/* ---- plain device-memory plumbing for callers without a HIP runtime of their own --- */
+int blur_malloc(blur_ctx* ctx, void** d_ptr, size_t bytes);
+int blur_free(blur_ctx* ctx, void* d_ptr);
+int blur_memcpy_h2d(blur_ctx* ctx, void* d_dst, const void* src, size_t bytes);   /* synchronous */
+int blur_memcpy_d2h(blur_ctx* ctx, void* dst, const void* d_src, size_t bytes);   /* synchronous */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLUR_AMD_H */

@@ -1,0 +1,57 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+@pytest.fixture(scope="session")
+def ctx():
+    """one BlurContext on cuda:0 for the whole GPU session (plans and spectra are cached in it)"""
+    if not _has_gpu():
+        pytest.skip("no GPU in this process")
+    import blur_algorithms_amd as B
+    c = B.BlurContext(0)
+    yield c
+    c.close()
+
+
+# ---- the parity contract (DESIGN.md "Parity") -------------------------------------------
+# float planes: |engine - float64 oracle| <= FLOAT_TOL grey levels (inputs in [0,255]);
+# u8 output: equal to the oracle's rounding except where the oracle's own value lies within
+# TIE_TOL of a rounding boundary (k + 0.5), and then off by exactly one.
+FLOAT_TOL = 2.5e-4
+TIE_TOL = 5e-4
+
+
+def assert_u8_parity(got, want_u8, want_planes):
+    """got, want_u8: [rows, cols, 3] uint8; want_planes: [3, rows, cols] float32 (oracle, before rounding)"""
+    got = np.asarray(got)
+    diff = got.astype(np.int32) - want_u8.astype(np.int32)
+    mism = diff != 0
+    if not mism.any():
+        return 0
+    assert np.abs(diff).max() <= 1, "u8 output differs from the oracle by more than one level"
+    v = np.moveaxis(np.asarray(want_planes, np.float64), 0, -1) + 0.5
+    dist = np.abs(v - np.round(v))
+    worst = dist[mism].max()
+    assert worst <= TIE_TOL, "u8 mismatch away from a rounding tie (distance %.3g)" % worst
+    frac = mism.mean()
+    assert frac < 2e-3, "too many tie-break mismatches: %.3g" % frac
+    return int(mism.sum())

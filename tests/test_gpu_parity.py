@@ -1,0 +1,169 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the float64 CPU oracle
+on the same seeded inputs.  Run on the MI355X box:  python -m pytest tests -m gpu -x -q"""
+import numpy as np
+import pytest
+
+from conftest import FLOAT_TOL, assert_u8_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_img(rows, cols, seed):
+    return np.random.default_rng(seed).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def test_library_is_the_hip_one(ctx):
+    import blur_algorithms_amd as B
+    import os
+    assert os.path.exists(B.LIB_PATH)
+    maps = open("/proc/self/maps").read()
+    assert "libblur_amd.so" in maps
+
+
+# sizes chosen so the FFT lengths cover radix 16/10/9/8/6/5/4/3/2 plans, odd dimensions
+# (ragged last row pair / last column strip) and both N0 != N1 and N0 == N1
+CASES = [
+    (64, 96, 3.0),      # N 96 / 128
+    (33, 47, 2.0),      # odd x odd, tiny
+    (100, 77, 5.0),     # odd cols
+    (101, 203, 4.0),
+    (270, 480, 20.0),   # BASELINE C2 at quarter scale
+    (512, 512, 5.0),    # BASELINE C1 geometry, N 576 / 576
+    (500, 748, 20.0),   # test_images "Baseline.jpg" geometry
+]
+
+
+@pytest.mark.parametrize("rows,cols,sigma", CASES)
+def test_rowpass_float_planes(ctx, rows, cols, sigma):
+    """row pass (Source.cpp:520-537) against the oracle's `resf` planes"""
+    torch = _torch()
+    from oracle import oracle as O
+    img = _rand_img(rows, cols, 11)
+    planes = ctx.rowpass(torch.from_numpy(img).cuda(), sigma).cpu().numpy()
+    for c in range(3):
+        _, inter = O.pffft_plane_f64(img[:, :, c].astype(np.float32), sigma, True, want_inter=True)
+        err = np.abs(planes[c].astype(np.float64) - inter).max()
+        assert err <= FLOAT_TOL, "channel %d: max |err| %.3g" % (c, err)
+
+
+@pytest.mark.parametrize("rows,cols,sigma", CASES)
+@pytest.mark.parametrize("quirk", [True, False])
+def test_pffft_u8c3(ctx, rows, cols, sigma, quirk):
+    """whole pffft_() on u8 BGR against the float64 oracle, Nyquist quirk on and off"""
+    torch = _torch()
+    from oracle import oracle as O
+    img = _rand_img(rows, cols, 7)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    out = torch.empty_like(t)
+    ctx.pffft_(t, sigma, out=out, nyquist_quirk=quirk)
+    assert_u8_parity(out.cpu().numpy(), want, planes)
+    # in place, like the reference
+    ctx.pffft_(t, sigma, nyquist_quirk=quirk)
+    assert torch.equal(t, out)
+
+
+@pytest.mark.parametrize("group", [2, 4, 8, 16])
+def test_column_group_sizes_agree(ctx, group):
+    """the column strip width is a tuning knob: results must not depend on it"""
+    torch = _torch()
+    img = torch.from_numpy(_rand_img(120, 90, 3)).cuda()
+    ref = ctx.pffft_(img, 4.0, out=torch.empty_like(img), col_group=8)
+    got = ctx.pffft_(img, 4.0, out=torch.empty_like(img), col_group=group)
+    assert torch.equal(ref, got)
+
+
+def test_pffft_plane_f32_config1(ctx):
+    """BASELINE config 1: 512x512 single-channel float32, sigma 5"""
+    torch = _torch()
+    from oracle import oracle as O
+    plane = np.random.default_rng(5).uniform(0, 255, (512, 512)).astype(np.float32)
+    want = O.pffft_plane_f64(plane, 5.0, True)
+    got = ctx.pffft_plane(torch.from_numpy(plane).cuda(), 5.0).cpu().numpy()
+    err = np.abs(got.astype(np.float64) - want).max()
+    assert err <= FLOAT_TOL, err
+    # host-pointer entry point gives the same bits
+    got_h = ctx.pffft_plane(plane, 5.0)
+    assert np.array_equal(got_h, got)
+
+
+def test_host_entry_point_matches_device(ctx):
+    torch = _torch()
+    img = _rand_img(90, 130, 2)
+    dev = ctx.pffft_(torch.from_numpy(img).cuda(), 6.0).cpu().numpy()
+    host = ctx.pffft_(img, 6.0)
+    assert np.array_equal(dev, host)
+
+
+def test_batch_equals_single_frames(ctx):
+    torch = _torch()
+    frames = torch.from_numpy(np.stack([_rand_img(72, 100, s) for s in range(4)])).cuda()
+    out = ctx.pffft_(frames, 5.0, out=torch.empty_like(frames))
+    for i in range(4):
+        one = ctx.pffft_(frames[i].contiguous(), 5.0, out=torch.empty_like(frames[i]))
+        assert torch.equal(out[i], one)
+
+
+def test_constant_image_is_preserved(ctx):
+    """DC gain: a constant image stays constant (kernel sums to 1, reflect padding).
+    Run without the Nyquist quirk, which adds +-255/N of checkerboard by design."""
+    torch = _torch()
+    img = torch.full((80, 112, 3), 200, dtype=torch.uint8, device="cuda")
+    out = ctx.pffft_(img, 7.0, out=torch.empty_like(img), nyquist_quirk=False)
+    assert int(out.min()) == 200 and int(out.max()) == 200
+
+
+def test_linearity_of_float_path(ctx):
+    """blur(a + b) == blur(a) + blur(b) up to round-off (size-independent property)"""
+    torch = _torch()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    a = (torch.rand((160, 224), generator=g) * 100).cuda()
+    b = (torch.rand((160, 224), generator=g) * 100).cuda()
+    lhs = ctx.pffft_plane(a + b, 9.0)
+    rhs = ctx.pffft_plane(a, 9.0) + ctx.pffft_plane(b, 9.0)
+    assert float((lhs - rhs).abs().max()) < 2 * FLOAT_TOL
+
+
+def test_errors_are_loud(ctx):
+    torch = _torch()
+    import blur_algorithms_amd as B
+    # the window is clamped to the LONGER side (Source.cpp:434), so a thin image gets
+    # pad 32 > rows - 1 = 3: out-of-buffer reads in the reference (README.md:33-38), refused here
+    thin = torch.zeros((4, 64, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(B.BlurError) as e:
+        ctx.pffft_(thin, 20.0)
+    assert e.value.code == 2
+    img = torch.zeros((16, 16, 3), dtype=torch.uint8, device="cuda")
+    with pytest.raises(B.BlurError):
+        ctx.pffft_(img, -1.0)
+    ctx.pffft_(img, 20.0)                # window clamped to 17, pad 8: fine
+
+
+def test_pieces_flip_block_and_interleave(ctx):
+    torch = _torch()
+    from oracle import oracle as O
+    w, h = 150, 70
+    plane = torch.arange(w * h, dtype=torch.float32, device="cuda")
+    got = ctx.flip_block(plane, w, h).cpu().numpy()
+    assert np.array_equal(got, O.flip_block(plane.cpu().numpy(), w, h))
+    img = _rand_img(37, 41, 9)
+    planes = ctx.deinterleave_BGR(torch.from_numpy(img).cuda())
+    assert np.array_equal(planes.cpu().numpy(), O.deinterleave_bgr(img))
+    vals = np.random.default_rng(1).uniform(0, 255.49, (3, 1000)).astype(np.float32)
+    got = ctx.interleave_BGR(torch.from_numpy(vals).cuda()).cpu().numpy()
+    assert np.array_equal(got, O.interleave_bgr(vals))
+
+
+@pytest.mark.parametrize("w,h,ch,ksize,passes", [(97, 61, 3, 9, 2), (128, 64, 1, 5, 3), (50, 40, 3, 41, 3), (33, 20, 3, 81, 1)])
+def test_fastboxblur(ctx, w, h, ch, ksize, passes):
+    torch = _torch()
+    from oracle import oracle as O
+    img = np.random.default_rng(4).integers(0, 256, (h, w, ch), dtype=np.uint8)
+    want = O.fastboxblur_u8(img, ksize, passes)
+    got = ctx.fastboxblur(torch.from_numpy(img.copy()).cuda(), ksize, passes).cpu().numpy()
+    assert np.array_equal(got, want)
