@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libblur_amd.so")
+LIB_PATH = os.environ.get("BLUR_AMD_LIB") or os.path.join(_HERE, "libblur_amd.so")   # BLUR_AMD_LIB: developer A/B builds
 
 BLUR_OK = 0
 ERR_NAMES = {1: "BLUR_ERR_INVALID", 2: "BLUR_ERR_UNSUPPORTED", 3: "BLUR_ERR_HIP", 4: "BLUR_ERR_NOMEM"}

@@ -93,11 +93,12 @@ class BlurContext:
         if rc:
             raise BlurError(rc, self._lib.blur_last_error(self._h).decode())
 
-    def _opts(self, nyquist_quirk=True, col_group=0):
+    def _opts(self, nyquist_quirk=True, col_group=0, force_generic=False):
         o = BlurOpts()
         self._lib.blur_opts_default(C.byref(o))
         o.nyquist_quirk = 1 if nyquist_quirk else 0
         o.col_group = int(col_group)
+        o.reserved[0] = 1 if force_generic else 0   # tests: run the run-time-planned kernels even where a specialised one exists
         return o
 
     def use_torch_stream(self):
@@ -120,13 +121,13 @@ class BlurContext:
         return dict(row_ms=ms[0], col_ms=ms[1], row_launches=n[0], col_launches=n[1])
 
     # -- pffft_(image, sigma): Source.cpp:429-570 -----------------------------------------
-    def pffft_(self, image, sigma, out=None, nyquist_quirk=True, col_group=0):
+    def pffft_(self, image, sigma, out=None, nyquist_quirk=True, col_group=0, force_generic=False):
         """Gaussian blur of a BGR/RGB uint8 image [rows, cols, 3] or a batch [n, rows, cols, 3].
 
         torch CUDA tensor: asynchronous on torch's current stream, returns `out`
         (default: in place, like the reference).  numpy array: host round trip, returns a new array.
         """
-        o = self._opts(nyquist_quirk, col_group)
+        o = self._opts(nyquist_quirk, col_group, force_generic)
         if isinstance(image, np.ndarray):
             a = np.ascontiguousarray(image, np.uint8)
             if a.ndim != 3 or a.shape[2] != 3:
@@ -166,10 +167,10 @@ class BlurContext:
         self._check(self._lib.blur_gaussian_f32c1_dev(self._h, t.data_ptr(), dst.data_ptr(), t.shape[0], t.shape[1], float(sigma), C.byref(o)))
         return dst
 
-    def rowpass(self, image, sigma, nyquist_quirk=True):
+    def rowpass(self, image, sigma, nyquist_quirk=True, force_generic=False):
         """row pass only: uint8 [rows, cols, 3] CUDA tensor -> float32 [3, rows, cols] (Source.cpp:520-537)"""
         import torch
-        o = self._opts(nyquist_quirk)
+        o = self._opts(nyquist_quirk, 0, force_generic)
         rows, cols = image.shape[0], image.shape[1]
         planes = torch.empty((3, rows, cols), dtype=torch.float32, device=image.device)
         self.use_torch_stream()

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../include/blur_amd.h"
+#include "fast_registry.hpp"
 #include "fft_engine.hpp"
 #include "host_math.hpp"
 
@@ -250,14 +251,15 @@ struct DevicePlan {
     FftPlan host;
     DevPlan dev{};
     float2* d_tw = nullptr;
+    const FastEntry* fast = nullptr;   // compile-time specialised kernels for this length, if any
 };
 
 struct blur_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    std::map<int, std::unique_ptr<DevicePlan>> plans;
-    // (n, ksize, quirk, sigma bits) -> device multiplier table in position order
+    std::map<int, std::unique_ptr<DevicePlan>> plans;   // key: 2*n + (fast ? 1 : 0)
+    // (plan key, ksize, quirk, sigma bits) -> device multiplier table in position order
     std::map<std::tuple<int, int, int, uint64_t>, float*> spectra;
     float* work = nullptr;       // float planes of one frame
     size_t work_bytes = 0;
@@ -287,12 +289,16 @@ static int fail(blur_ctx* ctx, int code, const char* msg)
     return code;
 }
 
-static int get_plan(blur_ctx* ctx, int n, DevicePlan** out)
+static int get_plan(blur_ctx* ctx, int n, bool want_fast, DevicePlan** out)
 {
-    auto it = ctx->plans.find(n);
+    const FastEntry* fe = want_fast ? find_fast_entry(n) : nullptr;
+    const int key = 2 * n + (fe ? 1 : 0);
+    auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) { *out = it->second.get(); return BLUR_OK; }
     auto dp = std::make_unique<DevicePlan>();
-    if (!make_plan(n, dp->host)) return fail(ctx, BLUR_ERR_UNSUPPORTED, "FFT length is not 2^a 3^b 5^c");
+    dp->fast = fe;
+    const bool ok = fe ? make_plan_radices(n, fe->radix, fe->npass, dp->host) : make_plan(n, dp->host);
+    if (!ok) return fail(ctx, BLUR_ERR_UNSUPPORTED, "FFT length is not 2^a 3^b 5^c");
     dp->dev.n = n;
     dp->dev.npass = dp->host.npass;
     for (int i = 0; i < dp->host.npass; ++i) {
@@ -305,7 +311,7 @@ static int get_plan(blur_ctx* ctx, int n, DevicePlan** out)
     if (!dp->host.tw.empty())
         HIP_TRY(ctx, hipMemcpy(dp->d_tw, dp->host.tw.data(), dp->host.tw.size() * sizeof(float), hipMemcpyHostToDevice));
     *out = dp.get();
-    ctx->plans[n] = std::move(dp);
+    ctx->plans[key] = std::move(dp);
     return BLUR_OK;
 }
 
@@ -313,7 +319,7 @@ static int get_spectrum(blur_ctx* ctx, const DevicePlan& plan, double sigma, int
 {
     uint64_t bits;
     std::memcpy(&bits, &sigma, sizeof bits);
-    const auto key = std::make_tuple(plan.dev.n, ksize, quirk ? 1 : 0, bits);
+    const auto key = std::make_tuple(2 * plan.dev.n + (plan.fast ? 1 : 0), ksize, quirk ? 1 : 0, bits);
     auto it = ctx->spectra.find(key);
     if (it != ctx->spectra.end()) { *out = it->second; return BLUR_OK; }
     const int n = plan.dev.n;
@@ -438,9 +444,10 @@ struct Prepared {
     DevicePlan *row = nullptr, *col = nullptr;
     float *m_row = nullptr, *m_col = nullptr;
     int col_group = 0;
+    int col_fast_c = 0;     // > 0: complex lines per workgroup of the specialised column kernel
 };
 
-static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p)
+static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p, bool u8c3 = true)
 {
     if (!ctx) return BLUR_ERR_INVALID;
     if (rows <= 0 || cols <= 0 || !(sigma > 0)) return fail(ctx, BLUR_ERR_INVALID, "rows, cols and sigma must be positive");
@@ -450,11 +457,39 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         return fail(ctx, BLUR_ERR_UNSUPPORTED, "pad > min(rows, cols) - 1: reflect-101 would read outside the image (README.md:33-38)");
     const bool quirk = opts ? opts->nyquist_quirk != 0 : true;
     p.col_group = opts ? opts->col_group : 0;
-    if (int rc = get_plan(ctx, p.sz.n_row, &p.row)) return rc;
-    if (int rc = get_plan(ctx, p.sz.n_col, &p.col)) return rc;
+    const bool allow_fast = u8c3 && !(opts && opts->reserved[0] == 1);   // reserved[0] = 1: force the generic kernels (tests)
+    // the specialised column kernel needs its strip (C complex lines + pixel stage) to fit in LDS
+    if (allow_fast)
+        if (const FastEntry* fe = find_fast_entry(p.sz.n_col)) {
+            int C = p.col_group > 0 ? (p.col_group >= 8 ? 4 : 2) : 4;
+            while (C >= 2 && fe->col_lds_bytes(rows, C) > kLdsLimit) C /= 2;
+            p.col_fast_c = C >= 2 ? C : 0;
+        }
+    if (int rc = get_plan(ctx, p.sz.n_row, allow_fast, &p.row)) return rc;
+    if (int rc = get_plan(ctx, p.sz.n_col, allow_fast && p.col_fast_c > 0, &p.col)) return rc;
     if (int rc = get_spectrum(ctx, *p.row, sigma, p.sz.kSize, quirk, &p.m_row)) return rc;
     if (int rc = get_spectrum(ctx, *p.col, sigma, p.sz.kSize, quirk, &p.m_col)) return rc;
     return BLUR_OK;
+}
+
+static int run_rowpass_u8c3(blur_ctx* ctx, const uint8_t* src, float* planes, int rows, int cols, const Prepared& p)
+{
+    if (p.row->fast) {
+        TimedLaunch t(ctx, 0);
+        HIP_TRY(ctx, p.row->fast->row_u8(ctx->stream, src, planes, rows, cols, p.sz.pad, p.row->d_tw, p.m_row));
+        return BLUR_OK;
+    }
+    return launch_rowpass<uint8_t, 3>(ctx, src, planes, rows, cols, p.sz.pad, *p.row, p.m_row);
+}
+
+static int run_colpass_u8c3(blur_ctx* ctx, const float* planes, uint8_t* dst, int rows, int cols, const Prepared& p)
+{
+    if (p.col->fast) {
+        TimedLaunch t(ctx, 1);
+        HIP_TRY(ctx, p.col->fast->col_u8(ctx->stream, planes, dst, rows, cols, p.sz.pad, p.col->d_tw, p.m_col, p.col_fast_c));
+        return BLUR_OK;
+    }
+    return launch_colpass<uint8_t, 3>(ctx, planes, dst, rows, cols, p.sz.pad, *p.col, p.m_col, p.col_group);
 }
 
 // ======================================================================================
@@ -587,8 +622,8 @@ int blur_gaussian_u8c3_batch_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d
     for (int f = 0; f < nframes; ++f) {
         const uint8_t* s = d_src + static_cast<size_t>(f) * px * 3;
         uint8_t* d = d_dst + static_cast<size_t>(f) * px * 3;
-        if (int rc = launch_rowpass<uint8_t, 3>(ctx, s, ctx->work, rows, cols, p.sz.pad, *p.row, p.m_row)) return rc;
-        if (int rc = launch_colpass<uint8_t, 3>(ctx, ctx->work, d, rows, cols, p.sz.pad, *p.col, p.m_col, p.col_group)) return rc;
+        if (int rc = run_rowpass_u8c3(ctx, s, ctx->work, rows, cols, p)) return rc;
+        if (int rc = run_colpass_u8c3(ctx, ctx->work, d, rows, cols, p)) return rc;
     }
     return BLUR_OK;
 }
@@ -603,7 +638,7 @@ int blur_gaussian_f32c1_dev(blur_ctx* ctx, const float* d_src, float* d_dst, int
     if (!ctx) return BLUR_ERR_INVALID;
     if (!d_src || !d_dst) return fail(ctx, BLUR_ERR_INVALID, "null plane pointer");
     Prepared p;
-    if (int rc = prepare(ctx, rows, cols, sigma, opts, p)) return rc;
+    if (int rc = prepare(ctx, rows, cols, sigma, opts, p, false)) return rc;
     const size_t px = static_cast<size_t>(rows) * cols;
     if (int rc = ensure_work(ctx, px * sizeof(float))) return rc;
     if (int rc = launch_rowpass<float, 1>(ctx, d_src, ctx->work, rows, cols, p.sz.pad, *p.row, p.m_row)) return rc;
@@ -616,7 +651,7 @@ int blur_rowpass_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, float* d_planes, 
     if (!d_src || !d_planes) return fail(ctx, BLUR_ERR_INVALID, "null pointer");
     Prepared p;
     if (int rc = prepare(ctx, rows, cols, sigma, opts, p)) return rc;
-    return launch_rowpass<uint8_t, 3>(ctx, d_src, d_planes, rows, cols, p.sz.pad, *p.row, p.m_row);
+    return run_rowpass_u8c3(ctx, d_src, d_planes, rows, cols, p);
 }
 
 int blur_gaussian_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int rows, int cols, double sigma, const blur_opts* opts)

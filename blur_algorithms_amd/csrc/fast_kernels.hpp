@@ -1,0 +1,483 @@
+// fast_kernels.hpp -- compile-time specialised row / column kernels for the FFT lengths the
+// BASELINE configs land on.  Same algorithm and data path as the generic kernels in
+// engine.hip (see there), but the plan (N and its radix sequence) is a template argument so
+// that every stride, trip count and table offset is a constant:
+//   * pass 0's twiddles (the only big table: N(1-1/R0) complex) live in REGISTERS: butterfly
+//     j of pass 0 is always done by the same thread, for every line the workgroup processes;
+//   * the pointwise multipliers of the fused middle pass live in registers the same way;
+//   * the small twiddle tables of the inner passes are copied to LDS once per workgroup;
+//   * row pass: pass 0 reads the u8 pixels straight from global memory (deinterleave +
+//     reflect-101 pad fused, Utils.hpp:159-184 / Source.cpp:525-529) and the last inverse
+//     pass stores the cropped float rows straight to global memory (Source.cpp:536);
+//   * column pass: the last inverse pass applies interleave_BGR's "+0.5f, truncate"
+//     (Utils.hpp:189,204-206) and writes bytes into the LDS pixel stage.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fft_engine.hpp"
+
+namespace blur_amd {
+
+// ---- static plan ---------------------------------------------------------------------
+template <int N_, int... Rs> struct StaticPlan {
+    static constexpr int N = N_;
+    static constexpr int P = sizeof...(Rs);
+    static constexpr int R[P] = { Rs... };
+    static constexpr int m(int i) { int len = N; for (int k = 0; k <= i; ++k) len /= R[k]; return len; }
+    static constexpr int nb(int i) { return N / R[i]; }
+    // offset of pass i's twiddles inside the plan's table (host layout, make_plan_radices)
+    static constexpr int tw_off(int i) { int off = 0; for (int k = 0; k < i; ++k) if (m(k) > 1) off += (R[k] - 1) * m(k); return off; }
+    // inner passes 1..P-2 go to LDS
+    static constexpr int lds_tw_begin() { return tw_off(1); }
+    static constexpr int lds_tw_count() { return P > 2 ? tw_off(P - 1) - tw_off(1) : 0; }
+    static constexpr bool valid() { int p = 1; for (int k = 0; k < P; ++k) p *= R[k]; return p == N && P >= 2 && P <= kMaxPassesDev; }
+};
+
+struct FastEntry {
+    int n;
+    int npass;
+    int radix[kMaxPassesDev];
+    hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* planes, int rows, int cols, int pad,
+                         const float2* tw, const float* mperm);
+    // C = complex lines per workgroup (strip width / 2): 1, 2, 4 or 8
+    hipError_t (*col_u8)(hipStream_t, const float* planes, uint8_t* dst, int rows, int cols, int pad,
+                         const float2* tw, const float* mperm, int C);
+    size_t (*col_lds_bytes)(int rows, int C);
+};
+
+__device__ __forceinline__ int fk_xcd_contiguous(int b, int nwg)
+{
+    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+}
+
+__device__ __forceinline__ int fk_reflect_src(int p, int pad, int len)
+{
+    const int i = p - pad;
+    if (i < 0) return -i;
+    if (i < len) return i;
+    if (i < len + pad) return 2 * (len - 1) - i;
+    return -1;
+}
+
+// ---- inner passes on LDS, flattened over (line, butterfly) ----------------------------------
+template <class PL, int I, int C, int T, bool INV>
+__device__ __forceinline__ void fk_inner_pass(float2* z, int zs, const float2* twl)
+{
+    constexpr int R = PL::R[I], m = PL::m(I), nb = PL::nb(I), total = nb * C;
+    constexpr int off = PL::tw_off(I) - PL::lds_tw_begin();
+#pragma unroll 1
+    for (int g = threadIdx.x; g < total; g += T) {
+        const int c = g / nb, b = g - c * nb;
+        const int blk = b / m, j = b - blk * m;
+        const int base = blk * (R * m) + j;
+        float2* zc = z + c * zs;
+        float2 v[R];
+        if constexpr (!INV) {
+#pragma unroll
+            for (int k = 0; k < R; ++k) v[k] = zc[phys(base + k * m)];
+            Bfly<R, false>::run(v);
+            zc[phys(base)] = v[0];
+#pragma unroll
+            for (int q = 1; q < R; ++q) zc[phys(base + q * m)] = cmul(v[q], twl[off + (q - 1) * m + j]);
+        } else {
+            v[0] = zc[phys(base)];
+#pragma unroll
+            for (int q = 1; q < R; ++q) v[q] = cmulc(zc[phys(base + q * m)], twl[off + (q - 1) * m + j]);
+            Bfly<R, true>::run(v);
+#pragma unroll
+            for (int k = 0; k < R; ++k) zc[phys(base + k * m)] = v[k];
+        }
+    }
+}
+
+template <class PL, int I, int C, int T, bool INV>
+__device__ __forceinline__ void fk_inner_passes(float2* z, int zs, const float2* twl)
+{
+    // forward: I = 1 .. P-2 ascending; inverse: P-2 .. 1 descending
+    if constexpr (I >= 1 && I <= PL::P - 2) {
+        fk_inner_pass<PL, I, C, T, INV>(z, zs, twl);
+        __syncthreads();
+        fk_inner_passes<PL, (INV ? I - 1 : I + 1), C, T, INV>(z, zs, twl);
+    }
+}
+
+// fused middle: last forward pass (m == 1) * multipliers * first inverse pass.
+// The multipliers of "my" butterflies are in registers (mm), IT_MID iterations of R each.
+template <class PL, int T, int C> struct MidRegs {
+    static constexpr int R = PL::R[PL::P - 1];
+    static constexpr int nb = PL::nb(PL::P - 1);
+    // per line: butterflies b = tid + T*it
+    static constexpr int IT = (nb + T - 1) / T;
+    float mm[IT][R];
+    __device__ __forceinline__ void load(const float* __restrict__ mperm)
+    {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int b = threadIdx.x + T * it;
+#pragma unroll
+            for (int q = 0; q < R; ++q) mm[it][q] = mperm[(b < nb ? b : nb - 1) * R + q];
+        }
+    }
+    __device__ __forceinline__ void run(float2* z, int zs) const
+    {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int b = threadIdx.x + T * it;
+            if (b < nb) {
+#pragma unroll 1
+                for (int c = 0; c < C; ++c) {
+                    float2* zc = z + c * zs;
+                    float2 v[R];
+#pragma unroll
+                    for (int k = 0; k < R; ++k) v[k] = zc[phys(b * R + k)];
+                    Bfly<R, false>::run(v);
+#pragma unroll
+                    for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mm[it][q]);
+                    Bfly<R, true>::run(v);
+#pragma unroll
+                    for (int k = 0; k < R; ++k) zc[phys(b * R + k)] = v[k];
+                }
+            }
+        }
+    }
+};
+
+// the same fused middle pass flattened over (line, butterfly), multipliers read from LDS
+template <class PL, int T, int C>
+__device__ __forceinline__ void fk_mid_lds(float2* z, int zs, const float* mpl)
+{
+    constexpr int R = PL::R[PL::P - 1], nb = PL::nb(PL::P - 1), total = nb * C;
+#pragma unroll 1
+    for (int g = threadIdx.x; g < total; g += T) {
+        const int c = g / nb, b = g - c * nb;
+        float2* zc = z + c * zs;
+        float2 v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = zc[phys(b * R + k)];
+        Bfly<R, false>::run(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mpl[b * R + q]);
+        Bfly<R, true>::run(v);
+#pragma unroll
+        for (int k = 0; k < R; ++k) zc[phys(b * R + k)] = v[k];
+    }
+}
+
+// pass-0 twiddles in registers: butterfly j = tid (+ T*it)
+template <class PL, int T> struct Pass0Regs {
+    static constexpr int R = PL::R[0];
+    static constexpr int m = PL::m(0);          // == nb(0): one block of length N
+    static constexpr int IT = (m + T - 1) / T;
+    float2 w[IT][R];                            // w[.][0] unused
+    __device__ __forceinline__ void load(const float2* __restrict__ tw, int j0)
+    {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int j = j0 + T * it;
+#pragma unroll
+            for (int q = 1; q < R; ++q) w[it][q] = tw[(q - 1) * m + (j < m ? j : m - 1)];   // unconditional: loads must not serialise
+        }
+    }
+};
+
+// ======================================================================================
+// row pass
+// ======================================================================================
+template <class PL, int T, int CH>
+__global__ __launch_bounds__(T, 3) void fast_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ planes,
+                                                     int rows, int cols, int pad, int npairs,
+                                                     const float2* __restrict__ tw, const float* __restrict__ mperm)
+{
+    static_assert(PL::valid(), "radices do not multiply to N");
+    constexpr int N = PL::N, P = PL::P;
+    constexpr int R0 = PL::R[0], m0 = PL::m(0);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* z = reinterpret_cast<float2*>(smem);
+    float2* twl = z + line_stride(N);
+    float* mpl = reinterpret_cast<float*>(twl + ((PL::lds_tw_count() + 1) & ~1));
+
+    Pass0Regs<PL, T> p0;
+    p0.load(tw, threadIdx.x);
+    for (int i = threadIdx.x; i < PL::lds_tw_count(); i += T) twl[i] = tw[PL::lds_tw_begin() + i];
+    for (int i = threadIdx.x; i < N; i += T) mpl[i] = mperm[i];
+
+    for (int pair = fk_xcd_contiguous(blockIdx.x, gridDim.x); pair < npairs; pair += gridDim.x) {
+        const int r0 = 2 * pair;
+        const bool two = r0 + 1 < rows;
+        const uint8_t* row_a = src + static_cast<size_t>(r0) * cols * CH;
+        const uint8_t* row_b = row_a + (two ? static_cast<size_t>(cols) * CH : 0);
+        for (int c = 0; c < CH; ++c) {
+            __syncthreads();   // previous line's readers are done with z (and twl is visible)
+            // ---- pass 0: global u8 -> butterfly -> twiddle -> LDS
+#pragma unroll
+            for (int it = 0; it < Pass0Regs<PL, T>::IT; ++it) {
+                const int j = threadIdx.x + T * it;
+                if (j < m0) {
+                    // every load is unconditional (clamped index, value masked afterwards) so that
+                    // all 2*R0 of them are in flight together instead of one round trip each
+                    uint8_t pa[R0], pb[R0];
+                    bool ok[R0];
+#pragma unroll
+                    for (int k = 0; k < R0; ++k) {
+                        const int x = fk_reflect_src(j + k * m0, pad, cols);
+                        ok[k] = x >= 0;
+                        const int xi = (x >= 0 ? x : 0) * CH + c;
+                        pa[k] = row_a[xi];
+                        pb[k] = row_b[xi];
+                    }
+                    float2 v[R0];
+#pragma unroll
+                    for (int k = 0; k < R0; ++k)
+                        v[k] = make_float2(ok[k] ? static_cast<float>(pa[k]) : 0.f, (ok[k] && two) ? static_cast<float>(pb[k]) : 0.f);
+                    Bfly<R0, false>::run(v);
+                    z[phys(j)] = v[0];
+#pragma unroll
+                    for (int q = 1; q < R0; ++q) z[phys(j + q * m0)] = cmul(v[q], p0.w[it][q]);
+                }
+            }
+            __syncthreads();
+            fk_inner_passes<PL, 1, 1, T, false>(z, 0, twl);
+            fk_mid_lds<PL, T, 1>(z, 0, mpl);
+            __syncthreads();
+            fk_inner_passes<PL, P - 2, 1, T, true>(z, 0, twl);
+            // ---- inverse pass 0: LDS -> conj twiddle -> butterfly -> cropped float rows
+            float* out_a = planes + (static_cast<size_t>(c) * rows + r0) * cols;
+            float* out_b = out_a + cols;
+#pragma unroll
+            for (int it = 0; it < Pass0Regs<PL, T>::IT; ++it) {
+                const int j = threadIdx.x + T * it;
+                if (j < m0) {
+                    float2 v[R0];
+                    v[0] = z[phys(j)];
+#pragma unroll
+                    for (int q = 1; q < R0; ++q) v[q] = cmulc(z[phys(j + q * m0)], p0.w[it][q]);
+                    Bfly<R0, true>::run(v);
+#pragma unroll
+                    for (int k = 0; k < R0; ++k) {
+                        const int x = j + k * m0 - pad;
+                        if (x >= 0 && x < cols) {
+                            out_a[x] = v[k].x;
+                            if (two) out_b[x] = v[k].y;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ======================================================================================
+// column pass
+// ======================================================================================
+template <class PL, int T, int C, int CH>
+__global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ planes, uint8_t* __restrict__ dst,
+                                                     int rows, int cols, int pad, int nstrips,
+                                                     const float2* __restrict__ tw, const float* __restrict__ mperm)
+{
+    static_assert(PL::valid(), "radices do not multiply to N");
+    constexpr int N = PL::N, P = PL::P, G = 2 * C;
+    constexpr int R0 = PL::R[0], m0 = PL::m(0);
+    // pass 0: K thread groups of m0 butterflies, group gi takes lines gi, gi+K, ...
+    constexpr int IT0 = Pass0Regs<PL, T>::IT;
+    constexpr int K = IT0 == 1 ? (T / m0 > C ? C : T / m0) : 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* z = reinterpret_cast<float2*>(smem);
+    constexpr int zs = line_stride(N);
+    float2* twl = z + C * zs;
+    float* mpl = reinterpret_cast<float*>(twl + ((PL::lds_tw_count() + 1) & ~1));         // N multipliers, position order
+    uint8_t* stage = reinterpret_cast<uint8_t*>(mpl + N);                                  // [rows][G*CH] bytes
+
+    const int gi = IT0 == 1 ? threadIdx.x / m0 : 0;
+    const int j0 = IT0 == 1 ? threadIdx.x - gi * m0 : threadIdx.x;
+    const bool p0_active = IT0 > 1 || gi < K;
+    Pass0Regs<PL, T> p0;
+    p0.load(tw, j0);
+    for (int i = threadIdx.x; i < PL::lds_tw_count(); i += T) twl[i] = tw[PL::lds_tw_begin() + i];
+    for (int i = threadIdx.x; i < N; i += T) mpl[i] = mperm[i];
+
+    for (int strip = fk_xcd_contiguous(blockIdx.x, gridDim.x); strip < nstrips; strip += gridDim.x) {
+        const int x0 = strip * G;
+        for (int ch = 0; ch < CH; ++ch) {
+            const float* plane = planes + static_cast<size_t>(ch) * rows * cols;
+            __syncthreads();   // z free again (previous channel's inverse pass 0 has read it)
+            // ---- gather: line l, position p  <-  plane[reflect(p)][x0 + 2l .. +1]
+            const bool full = x0 + G <= cols && (cols & 1) == 0;
+            if (full) {
+                // unconditional 8-byte loads (clamped row, masked value): the unrolled loop keeps
+                // several independent loads in flight per thread
+#pragma unroll 8
+                for (int idx = threadIdx.x; idx < N * C; idx += T) {
+                    const int p = idx / C, l = idx - p * C;
+                    const int r = fk_reflect_src(p, pad, rows);
+                    const float2 t = *reinterpret_cast<const float2*>(plane + static_cast<size_t>(r >= 0 ? r : 0) * cols + x0 + 2 * l);
+                    z[l * zs + phys(p)] = r >= 0 ? t : make_float2(0.f, 0.f);
+                }
+            } else {
+#pragma unroll 4
+                for (int idx = threadIdx.x; idx < N * C; idx += T) {
+                    const int p = idx / C, l = idx - p * C;
+                    const int r = fk_reflect_src(p, pad, rows);
+                    const int col = x0 + 2 * l;
+                    const float* s = plane + static_cast<size_t>(r >= 0 ? r : 0) * cols;
+                    const float a = s[col < cols ? col : cols - 1], b = s[col + 1 < cols ? col + 1 : cols - 1];
+                    z[l * zs + phys(p)] = make_float2((r >= 0 && col < cols) ? a : 0.f, (r >= 0 && col + 1 < cols) ? b : 0.f);
+                }
+            }
+            __syncthreads();
+            // ---- pass 0 (register twiddles)
+            if (p0_active) {
+#pragma unroll
+                for (int it = 0; it < IT0; ++it) {
+                    const int j = j0 + T * it;
+                    if (j < m0) {
+#pragma unroll 1
+                        for (int c = gi; c < C; c += K) {
+                            float2* zc = z + c * zs;
+                            float2 v[R0];
+#pragma unroll
+                            for (int k = 0; k < R0; ++k) v[k] = zc[phys(j + k * m0)];
+                            Bfly<R0, false>::run(v);
+                            zc[phys(j)] = v[0];
+#pragma unroll
+                            for (int q = 1; q < R0; ++q) zc[phys(j + q * m0)] = cmul(v[q], p0.w[it][q]);
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            fk_inner_passes<PL, 1, C, T, false>(z, zs, twl);
+            fk_mid_lds<PL, T, C>(z, zs, mpl);
+            __syncthreads();
+            fk_inner_passes<PL, P - 2, C, T, true>(z, zs, twl);
+            // ---- inverse pass 0 -> "+0.5f, truncate" -> pixel stage (Utils.hpp:189,204-206)
+            if (p0_active) {
+#pragma unroll
+                for (int it = 0; it < IT0; ++it) {
+                    const int j = j0 + T * it;
+                    if (j < m0) {
+#pragma unroll 1
+                        for (int c = gi; c < C; c += K) {
+                            const float2* zc = z + c * zs;
+                            float2 v[R0];
+                            v[0] = zc[phys(j)];
+#pragma unroll
+                            for (int q = 1; q < R0; ++q) v[q] = cmulc(zc[phys(j + q * m0)], p0.w[it][q]);
+                            Bfly<R0, true>::run(v);
+#pragma unroll
+                            for (int k = 0; k < R0; ++k) {
+                                const int r = j + k * m0 - pad;
+                                if (r >= 0 && r < rows) {
+                                    uint8_t* s = stage + (static_cast<size_t>(r) * G + 2 * c) * CH + ch;
+                                    s[0] = static_cast<uint8_t>(static_cast<int>(v[k].x + 0.5f));
+                                    s[CH] = static_cast<uint8_t>(static_cast<int>(v[k].y + 0.5f));
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- write the strip as whole pixels: G*CH contiguous bytes per image row
+        constexpr int RB = G * CH;
+        if (x0 + G <= cols && ((cols * CH) & 3) == 0 && (RB & 3) == 0) {
+            constexpr int RD = RB / 4;
+            const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
+            for (int idx = threadIdx.x; idx < rows * RD; idx += T) {
+                const int r = idx / RD, d = idx - r * RD;
+                uint32_t* o = reinterpret_cast<uint32_t*>(dst + (static_cast<size_t>(r) * cols + x0) * CH);
+                o[d] = s32[idx];
+            }
+        } else {
+            const int wbytes = (cols - x0 < G ? cols - x0 : G) * CH;
+            for (int idx = threadIdx.x; idx < rows * RB; idx += T) {
+                const int r = idx / RB, b = idx - r * RB;
+                if (b < wbytes) dst[(static_cast<size_t>(r) * cols + x0) * CH + b] = stage[idx];
+            }
+        }
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------
+template <class PL> size_t fk_row_lds()
+{
+    return (static_cast<size_t>(line_stride(PL::N)) + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) + static_cast<size_t>(PL::N) * sizeof(float);
+}
+
+template <class PL, int C> size_t fk_col_lds(int rows)
+{
+    return (static_cast<size_t>(C) * line_stride(PL::N) + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) +
+           static_cast<size_t>(PL::N) * sizeof(float) + static_cast<size_t>(rows) * 2 * C * 3 + 16;
+}
+
+template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uint8_t* src, float* planes, int rows, int cols, int pad,
+                                               const float2* tw, const float* mperm)
+{
+    const size_t lds = fk_row_lds<PL>();
+    auto kern = fast_rowpass_u8<PL, T, 3>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    const int npairs = (rows + 1) / 2;
+    hipLaunchKernelGGL(kern, dim3(npairs), dim3(T), lds, st, src, planes, rows, cols, pad, npairs, tw, mperm);
+    return hipGetLastError();
+}
+
+template <class PL, int T, int C> hipError_t fk_launch_col_u8_c(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad,
+                                                         const float2* tw, const float* mperm)
+{
+    const size_t lds = fk_col_lds<PL, C>(rows);
+    auto kern = fast_colpass_u8<PL, T, C, 3>;
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    const int nstrips = (cols + 2 * C - 1) / (2 * C);
+    hipLaunchKernelGGL(kern, dim3(nstrips), dim3(T), lds, st, planes, dst, rows, cols, pad, nstrips, tw, mperm);
+    return hipGetLastError();
+}
+
+template <class PL, int T> hipError_t fk_launch_col_u8(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad,
+                                               const float2* tw, const float* mperm, int C)
+{
+    switch (C) {
+    case 4: return fk_launch_col_u8_c<PL, T, 4>(st, planes, dst, rows, cols, pad, tw, mperm);
+    case 2: return fk_launch_col_u8_c<PL, T, 2>(st, planes, dst, rows, cols, pad, tw, mperm);
+    default: return hipErrorInvalidValue;
+    }
+}
+
+template <class PL> size_t fk_col_lds_bytes(int rows, int C)
+{
+    switch (C) {
+    case 4: return fk_col_lds<PL, 4>(rows);
+    case 2: return fk_col_lds<PL, 2>(rows);
+    default: return ~static_cast<size_t>(0);
+    }
+}
+
+template <class PL, int TROW, int TCOL> FastEntry fk_make_entry()
+{
+    FastEntry e{};
+    e.n = PL::N;
+    e.npass = PL::P;
+    for (int i = 0; i < PL::P; ++i) e.radix[i] = PL::R[i];
+    e.row_u8 = fk_launch_row_u8<PL, TROW>;
+    e.col_u8 = fk_launch_col_u8<PL, TCOL>;
+    e.col_lds_bytes = fk_col_lds_bytes<PL>;
+    return e;
+}
+
+}  // namespace blur_amd
+
+// one translation unit per FFT length: BLUR_FAST_INSTANCE(4000, TROW, TCOL, 16, 10, 25)
+#define BLUR_FAST_INSTANCE(NN, TROW, TCOL, ...)                                                            \
+    namespace blur_amd {                                                                         \
+    const FastEntry* fast_entry_##NN()                                                           \
+    {                                                                                            \
+        static const FastEntry e = fk_make_entry<StaticPlan<NN, __VA_ARGS__>, TROW, TCOL>();               \
+        return &e;                                                                               \
+    }                                                                                            \
+    }

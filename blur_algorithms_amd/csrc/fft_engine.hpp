@@ -190,11 +190,17 @@ template <bool INV> struct Bfly<8, INV> { static BLUR_HD void run(float2* v) { B
 template <bool INV> struct Bfly<9, INV> { static BLUR_HD void run(float2* v) { BflyComposite<3, 3, INV>::run(v); } };
 template <bool INV> struct Bfly<10, INV> { static BLUR_HD void run(float2* v) { BflyComposite<2, 5, INV>::run(v); } };
 template <bool INV> struct Bfly<16, INV> { static BLUR_HD void run(float2* v) { BflyComposite<4, 4, INV>::run(v); } };
+// larger composites, used by the compile-time plans of fast_kernels.hpp (3 passes for every BASELINE length)
+template <bool INV> struct Bfly<12, INV> { static BLUR_HD void run(float2* v) { BflyComposite<3, 4, INV>::run(v); } };
+template <bool INV> struct Bfly<15, INV> { static BLUR_HD void run(float2* v) { BflyComposite<3, 5, INV>::run(v); } };
+template <bool INV> struct Bfly<18, INV> { static BLUR_HD void run(float2* v) { BflyComposite<2, 9, INV>::run(v); } };
+template <bool INV> struct Bfly<20, INV> { static BLUR_HD void run(float2* v) { BflyComposite<4, 5, INV>::run(v); } };
+template <bool INV> struct Bfly<25, INV> { static BLUR_HD void run(float2* v) { BflyComposite<5, 5, INV>::run(v); } };
 
 // ---- LDS addressing: element i of a line lives at phys(i).  One spare element per 32
 // breaks the power-of-two strides of the late passes (bank conflicts).
-BLUR_HD int phys(int i) { return i + (i >> 5); }
-BLUR_HD int line_stride(int n) { return phys(n) + 1; }   // elements per line buffer
+__host__ __device__ constexpr int phys(int i) { return i + (i >> 5); }
+__host__ __device__ constexpr int line_stride(int n) { return phys(n) + 1; }   // elements per line buffer
 
 // ---- passes.  z: C line buffers of `zs` complex elements each.  Butterfly g of a pass
 // with block length R*m: blk = g / m, j = g % m, elements base + k*m, base = blk*R*m + j.
@@ -296,6 +302,13 @@ BLUR_HD void run_pass(int kind, int R, float2* z, int zs, int n, int m, const fl
     case 9: run_pass_r<9, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
     case 10: run_pass_r<10, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
     case 16: run_pass_r<16, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
+#ifdef BLUR_ENGINE_ALL_RADICES   // CPU harness only: the generic kernels never plan these
+    case 12: run_pass_r<12, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
+    case 15: run_pass_r<15, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
+    case 18: run_pass_r<18, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
+    case 20: run_pass_r<20, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
+    case 25: run_pass_r<25, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
+#endif
     default: break;
     }
 }

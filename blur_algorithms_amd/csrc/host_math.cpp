@@ -127,7 +127,17 @@ bool make_plan(int n, FftPlan& p)
 {
     std::vector<int> rad;
     choose_radices(n, rad);
-    if (n < 2 || rad.empty() || static_cast<int>(rad.size()) > kMaxPasses) return false;
+    if (n < 2 || rad.empty()) return false;
+    return make_plan_radices(n, rad.data(), static_cast<int>(rad.size()), p);
+}
+
+bool make_plan_radices(int n, const int* radices, int npass, FftPlan& p)
+{
+    if (n < 2 || npass < 1 || npass > kMaxPasses) return false;
+    long long prod = 1;
+    for (int i = 0; i < npass; ++i) prod *= radices[i];
+    if (prod != n) return false;
+    const std::vector<int> rad(radices, radices + npass);
     p = FftPlan{};
     p.n = n;
     p.npass = static_cast<int>(rad.size());

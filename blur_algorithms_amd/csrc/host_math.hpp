@@ -45,6 +45,8 @@ struct FftPlan {
 };
 // returns false if n has a prime factor other than 2, 3, 5
 bool make_plan(int n, FftPlan& plan);
+// same with an explicit radix sequence (the compile-time plans of fast_kernels.hpp)
+bool make_plan_radices(int n, const int* radices, int npass, FftPlan& plan);
 
 // multiplier table in POSITION order for a complex FFT of length n:
 // mperm[pos] = m[min(f, n-f)], f = freq_of_pos[pos]; with `quirk`, f == n/2 uses m[0]

@@ -68,6 +68,51 @@ def test_pffft_u8c3(ctx, rows, cols, sigma, quirk):
     assert torch.equal(t, out)
 
 
+# Shapes whose FFT lengths have compile-time specialised kernels (fast_kernels.hpp): thin images
+# keep the oracle cheap while the long side hits 4000 / 2304 / 1280 / 4320 / 2560 as row or
+# column length; odd sizes exercise the single last row and the ragged last column strip.
+FAST_CASES = [
+    (70, 3840, 20.0),     # row 4000 (column generic)
+    (71, 3839, 20.0),     # row 4000, odd x odd
+    (2160, 70, 20.0),     # column 2304
+    (2159, 67, 20.0),     # column 2304, odd x odd
+    (66, 1920, 20.0),     # row 2304
+    (1080, 66, 20.0),     # column 1280
+    (170, 3840, 50.0),    # row 4320
+    (2160, 170, 50.0),    # column 2560
+    (1080, 1920, 20.0),   # BASELINE C2 whole: 2304 / 1280
+]
+
+
+@pytest.mark.parametrize("rows,cols,sigma", FAST_CASES)
+def test_specialised_lengths(ctx, rows, cols, sigma):
+    torch = _torch()
+    from oracle import oracle as O
+    img = _rand_img(rows, cols, 21)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, True, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    got = ctx.pffft_(t, sigma, out=torch.empty_like(t))
+    assert_u8_parity(got.cpu().numpy(), want, planes)
+    gen = ctx.pffft_(t, sigma, out=torch.empty_like(t), force_generic=True)
+    assert_u8_parity(gen.cpu().numpy(), want, planes)
+    # float planes of the specialised row pass against the oracle's `resf`
+    rp = ctx.rowpass(t, sigma).cpu().numpy()
+    _, inter = O.pffft_plane_f64(img[:, :, 1].astype(np.float32), sigma, True, want_inter=True)
+    assert np.abs(rp[1].astype(np.float64) - inter).max() <= FLOAT_TOL
+
+
+def test_metric_frame_4k_sigma20(ctx):
+    """the metric's own configuration, whole frame against the float64 oracle"""
+    torch = _torch()
+    from oracle import oracle as O
+    img = _rand_img(2160, 3840, 99)
+    want, planes = O.pffft_blur_u8c3_f64(img, 20.0, True, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    got = ctx.pffft_(t, 20.0, out=torch.empty_like(t)).cpu().numpy()
+    n = assert_u8_parity(got, want, planes)
+    print("4K sigma=20: %d of %d bytes differ (ties)" % (n, got.size))
+
+
 @pytest.mark.parametrize("group", [2, 4, 8, 16])
 def test_column_group_sizes_agree(ctx, group):
     """the column strip width is a tuning knob: results must not depend on it"""

@@ -1,0 +1,26 @@
+#!/bin/bash
+# tools/build_variant.sh NAME "N TROW TCOL R,R,R" ...   [env: VFLAGS="-D..."]
+# Builds blur_algorithms_amd/variants/libblur_amd_NAME.so with the given compile-time plans
+# (any length not listed keeps the plan of csrc/fast_N.hip).  For A/B runs on the GPU box:
+#   BLUR_AMD_LIB=blur_algorithms_amd/variants/libblur_amd_NAME.so python tools/kbench.py
+set -e
+NAME=$1; shift
+CS=/root/repo/blur_algorithms_amd/csrc
+BD=$CS/build_$NAME
+mkdir -p $BD /root/repo/blur_algorithms_amd/variants
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$CS $VFLAGS"
+for f in $CS/fast_*.hip; do cp $f $BD/; done
+for spec in "$@"; do set -- $spec
+cat > $BD/fast_$1.hip <<EOT
+#include "fast_kernels.hpp"
+BLUR_FAST_INSTANCE($1, $2, $3, $4)
+EOT
+done
+pids=""
+for f in $BD/fast_*.hip; do /opt/rocm/bin/hipcc $FLAGS -c $f -o ${f%.hip}.o & pids="$pids $!"; done
+/opt/rocm/bin/hipcc $FLAGS -c $CS/engine.hip -o $BD/engine.o & pids="$pids $!"
+/opt/rocm/bin/hipcc $FLAGS -x c++ -c $CS/host_math.cpp -o $BD/host_math.o & pids="$pids $!"
+for p in $pids; do wait $p; done
+/opt/rocm/bin/hipcc $FLAGS -shared -o /root/repo/blur_algorithms_amd/variants/libblur_amd_$NAME.so $BD/*.o
+rm -rf $BD
+echo built variants/libblur_amd_$NAME.so
