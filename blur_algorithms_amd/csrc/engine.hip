@@ -261,15 +261,17 @@ struct blur_ctx {
     std::map<int, std::unique_ptr<DevicePlan>> plans;   // key: 2*n + (fast ? 1 : 0)
     // (plan key, ksize, quirk, sigma bits) -> device multiplier table in position order
     std::map<std::tuple<int, int, int, uint64_t>, float*> spectra;
+    std::map<int, float*> last_spectrum;   // n -> most recent table (diagnostic stamp read-back)
     float* work = nullptr;       // float planes of one frame
     size_t work_bytes = 0;
     uint8_t* box_tmp = nullptr;
     size_t box_bytes = 0;
     bool timing = false;
-    std::vector<std::tuple<hipEvent_t, hipEvent_t, int>> ev_busy;
+    std::vector<std::tuple<hipEvent_t, hipEvent_t, int, int>> ev_busy;   // start, stop, kernel (0 row / 1 column), frames
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     double ms[2] = { 0, 0 };
     int launches[2] = { 0, 0 };
+    int frames[2] = { 0, 0 };
 };
 
 static thread_local std::string g_create_err;
@@ -327,9 +329,12 @@ static int get_spectrum(blur_ctx* ctx, const DevicePlan& plan, double sigma, int
     kernel_multipliers(sigma, ksize, n, m.data());
     permuted_multipliers(plan.host, m.data(), quirk, mp.data());
     float* d = nullptr;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(float) * n));
+    // the tail behind the table is only written by -DFK_STAMPS diagnostic builds
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(float) * (n + kStampTailFloats)));
+    HIP_TRY(ctx, hipMemset(d, 0, sizeof(float) * (n + kStampTailFloats)));
     HIP_TRY(ctx, hipMemcpy(d, mp.data(), sizeof(float) * n, hipMemcpyHostToDevice));
     ctx->spectra[key] = d;
+    ctx->last_spectrum[plan.dev.n] = d;
     *out = d;
     return BLUR_OK;
 }
@@ -353,6 +358,7 @@ static int timing_drain(blur_ctx* ctx)
         HIP_TRY(ctx, hipEventElapsedTime(&ms, a, b));
         ctx->ms[std::get<2>(t)] += ms;
         ctx->launches[std::get<2>(t)] += 1;
+        ctx->frames[std::get<2>(t)] += std::get<3>(t);
         ctx->ev_free.emplace_back(a, b);
     }
     ctx->ev_busy.clear();
@@ -360,8 +366,8 @@ static int timing_drain(blur_ctx* ctx)
 }
 
 struct TimedLaunch {
-    blur_ctx* ctx; int which; hipEvent_t a = nullptr, b = nullptr; bool on;
-    TimedLaunch(blur_ctx* c, int w) : ctx(c), which(w), on(c->timing)
+    blur_ctx* ctx; int which; int nframes; hipEvent_t a = nullptr, b = nullptr; bool on;
+    TimedLaunch(blur_ctx* c, int w, int nf = 1) : ctx(c), which(w), nframes(nf), on(c->timing)
     {
         if (!on) return;
         if (ctx->ev_busy.size() >= 8192) timing_drain(ctx);
@@ -374,7 +380,7 @@ struct TimedLaunch {
     {
         if (!on) return;
         (void)hipEventRecord(b, ctx->stream);
-        ctx->ev_busy.emplace_back(a, b, which);
+        ctx->ev_busy.emplace_back(a, b, which, nframes);
     }
 };
 
@@ -472,24 +478,31 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     return BLUR_OK;
 }
 
-static int run_rowpass_u8c3(blur_ctx* ctx, const uint8_t* src, float* planes, int rows, int cols, const Prepared& p)
+// nframes frames back to back (planes: 3*rows*cols floats per frame)
+static int run_rowpass_u8c3(blur_ctx* ctx, const uint8_t* src, float* planes, int rows, int cols, int nframes, const Prepared& p)
 {
     if (p.row->fast) {
-        TimedLaunch t(ctx, 0);
-        HIP_TRY(ctx, p.row->fast->row_u8(ctx->stream, src, planes, rows, cols, p.sz.pad, p.row->d_tw, p.m_row));
+        TimedLaunch t(ctx, 0, nframes);
+        HIP_TRY(ctx, p.row->fast->row_u8(ctx->stream, src, planes, rows, cols, p.sz.pad, nframes, p.row->d_tw, p.m_row));
         return BLUR_OK;
     }
-    return launch_rowpass<uint8_t, 3>(ctx, src, planes, rows, cols, p.sz.pad, *p.row, p.m_row);
+    const size_t px = static_cast<size_t>(rows) * cols;
+    for (int f = 0; f < nframes; ++f)
+        if (int rc = launch_rowpass<uint8_t, 3>(ctx, src + f * px * 3, planes + f * px * 3, rows, cols, p.sz.pad, *p.row, p.m_row)) return rc;
+    return BLUR_OK;
 }
 
-static int run_colpass_u8c3(blur_ctx* ctx, const float* planes, uint8_t* dst, int rows, int cols, const Prepared& p)
+static int run_colpass_u8c3(blur_ctx* ctx, const float* planes, uint8_t* dst, int rows, int cols, int nframes, const Prepared& p)
 {
     if (p.col->fast) {
-        TimedLaunch t(ctx, 1);
-        HIP_TRY(ctx, p.col->fast->col_u8(ctx->stream, planes, dst, rows, cols, p.sz.pad, p.col->d_tw, p.m_col, p.col_fast_c));
+        TimedLaunch t(ctx, 1, nframes);
+        HIP_TRY(ctx, p.col->fast->col_u8(ctx->stream, planes, dst, rows, cols, p.sz.pad, nframes, p.col->d_tw, p.m_col, p.col_fast_c));
         return BLUR_OK;
     }
-    return launch_colpass<uint8_t, 3>(ctx, planes, dst, rows, cols, p.sz.pad, *p.col, p.m_col, p.col_group);
+    const size_t px = static_cast<size_t>(rows) * cols;
+    for (int f = 0; f < nframes; ++f)
+        if (int rc = launch_colpass<uint8_t, 3>(ctx, planes + f * px * 3, dst + f * px * 3, rows, cols, p.sz.pad, *p.col, p.m_col, p.col_group)) return rc;
+    return BLUR_OK;
 }
 
 // ======================================================================================
@@ -596,14 +609,15 @@ int blur_ctx_timing_enable(blur_ctx* ctx, int on)
     return BLUR_OK;
 }
 
-int blur_ctx_timing(blur_ctx* ctx, double out_ms[2], int out_launches[2], int reset)
+int blur_ctx_timing(blur_ctx* ctx, double out_ms[2], int out_launches[2], int out_frames[2], int reset)
 {
     if (!ctx) return BLUR_ERR_INVALID;
     if (int rc = timing_drain(ctx)) return rc;
     for (int i = 0; i < 2; ++i) {
         if (out_ms) out_ms[i] = ctx->ms[i];
         if (out_launches) out_launches[i] = ctx->launches[i];
-        if (reset) { ctx->ms[i] = 0; ctx->launches[i] = 0; }
+        if (out_frames) out_frames[i] = ctx->frames[i];
+        if (reset) { ctx->ms[i] = 0; ctx->launches[i] = 0; ctx->frames[i] = 0; }
     }
     return BLUR_OK;
 }
@@ -616,14 +630,20 @@ int blur_gaussian_u8c3_batch_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d
     Prepared p;
     if (int rc = prepare(ctx, rows, cols, sigma, opts, p)) return rc;
     const size_t px = static_cast<size_t>(rows) * cols;
-    if (int rc = ensure_work(ctx, px * 3 * sizeof(float))) return rc;
-    // frame by frame: the 12 B/px float intermediate of one frame stays in the 256 MiB
-    // Infinity Cache between the two kernels
-    for (int f = 0; f < nframes; ++f) {
+    // A few frames per launch pair: enough units to fill every CU evenly and to amortise the
+    // per-workgroup table loads, few enough that the 12 B/px float intermediate of the chunk
+    // still sits in the 256 MiB Infinity Cache when the column pass reads it back.
+    int chunk = opts && opts->reserved[1] > 0 ? opts->reserved[1] : static_cast<int>((192u << 20) / (px * 3 * sizeof(float)));
+    if (chunk < 1) chunk = 1;
+    if (chunk > nframes) chunk = nframes;
+    if (nframes == 0) return BLUR_OK;
+    if (int rc = ensure_work(ctx, px * 3 * sizeof(float) * chunk)) return rc;
+    for (int f = 0; f < nframes; f += chunk) {
+        const int nf = nframes - f < chunk ? nframes - f : chunk;
         const uint8_t* s = d_src + static_cast<size_t>(f) * px * 3;
         uint8_t* d = d_dst + static_cast<size_t>(f) * px * 3;
-        if (int rc = run_rowpass_u8c3(ctx, s, ctx->work, rows, cols, p)) return rc;
-        if (int rc = run_colpass_u8c3(ctx, ctx->work, d, rows, cols, p)) return rc;
+        if (int rc = run_rowpass_u8c3(ctx, s, ctx->work, rows, cols, nf, p)) return rc;
+        if (int rc = run_colpass_u8c3(ctx, ctx->work, d, rows, cols, nf, p)) return rc;
     }
     return BLUR_OK;
 }
@@ -651,7 +671,7 @@ int blur_rowpass_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, float* d_planes, 
     if (!d_src || !d_planes) return fail(ctx, BLUR_ERR_INVALID, "null pointer");
     Prepared p;
     if (int rc = prepare(ctx, rows, cols, sigma, opts, p)) return rc;
-    return run_rowpass_u8c3(ctx, d_src, d_planes, rows, cols, p);
+    return run_rowpass_u8c3(ctx, d_src, d_planes, rows, cols, 1, p);
 }
 
 int blur_gaussian_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int rows, int cols, double sigma, const blur_opts* opts)
@@ -771,6 +791,17 @@ int blur_fastboxblur_u8_host(blur_ctx* ctx, uint8_t* inout, int w, int h, int ch
     (void)hipFree(d);
     if (e != hipSuccess) { ctx->err = std::string("host fastboxblur: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
     return rc;
+}
+
+/* diagnostic builds (-DFK_STAMPS): copy the stamp tail behind the multiplier table of FFT length n */
+int blur_debug_read_stamps(blur_ctx* ctx, int n, unsigned long long* out, int count)
+{
+    if (!ctx || !out) return BLUR_ERR_INVALID;
+    auto it = ctx->last_spectrum.find(n);
+    if (it == ctx->last_spectrum.end() || count * sizeof(unsigned long long) > kStampTailFloats * sizeof(float)) return BLUR_ERR_INVALID;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out, it->second + n, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    return BLUR_OK;
 }
 
 int blur_malloc(blur_ctx* ctx, void** d_ptr, size_t bytes)

@@ -16,11 +16,55 @@
 
 #include "fft_engine.hpp"
 
+// tuning knobs (overridable per build for A/B runs: tools/build_variant.sh with VFLAGS)
+#ifndef FK_ROW_WAVES_PER_SIMD
+#define FK_ROW_WAVES_PER_SIMD 3     // __launch_bounds__ second argument of the row kernel
+#endif
+#ifndef FK_ROW_MID_GLOBAL
+#define FK_ROW_MID_GLOBAL 0         // 1: middle-pass multipliers straight from global/L1 instead of LDS
+#endif
+#ifndef FK_INNER_UNROLL
+#define FK_INNER_UNROLL 1           // butterflies of an inner / middle pass a thread keeps in flight together
+#endif
+#ifndef FK_HOIST_MAX_R
+#define FK_HOIST_MAX_R 10           // inner passes up to this radix read their twiddles up front
+#endif
+#ifndef FK_GATHER_UNROLL
+#define FK_GATHER_UNROLL 4          // independent strip-gather loads a thread keeps in flight (column kernel)
+#endif
+#define FK_PRAGMA(x) _Pragma(#x)
+#define FK_UNROLL(n) FK_PRAGMA(unroll n)
+
 namespace blur_amd {
 
+// Diagnostic builds only (-DFK_STAMPS): shader-clock stamps around the phases of a line, summed
+// per workgroup and written behind the multiplier table (the host allocates a tail for it).
+// No stamp executes in a normal build.
+constexpr int kStampSlots = 8;
+constexpr int kStampTailFloats = 1 << 16;
+#ifdef FK_STAMPS
+#define FK_STAMP(i)                                                   \
+    do {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                           \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        st_acc[i] += t_ - st_prev;                                    \
+        st_prev = t_;                                                 \
+    } while (0)
+#else
+#define FK_STAMP(i) do { } while (0)
+#endif
+
 // ---- static plan ---------------------------------------------------------------------
-template <int N_, int... Rs> struct StaticPlan {
+// PAD_: LDS line padding policy.  0 = none (element i at i); 1 = one spare element per 32
+// (fft_engine.hpp PL::at()): only plans whose inner passes stride by a multiple of 32 elements
+// need it, and it costs three VALU instructions per LDS address.
+template <int N_, int PAD_, int... Rs> struct StaticPlan {
     static constexpr int N = N_;
+    static constexpr int PAD = PAD_;
+    static __host__ __device__ constexpr int at(int i) { return PAD_ ? i + (i >> 5) : i; }
+    static __host__ __device__ constexpr int zs() { return at(N_) + 1; }
     static constexpr int P = sizeof...(Rs);
     static constexpr int R[P] = { Rs... };
     static constexpr int m(int i) { int len = N; for (int k = 0; k <= i; ++k) len /= R[k]; return len; }
@@ -37,10 +81,11 @@ struct FastEntry {
     int n;
     int npass;
     int radix[kMaxPassesDev];
-    hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* planes, int rows, int cols, int pad,
+    // nframes frames back to back (u8: rows*cols*3 bytes each; planes: 3*rows*cols floats each)
+    hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* planes, int rows, int cols, int pad, int nframes,
                          const float2* tw, const float* mperm);
-    // C = complex lines per workgroup (strip width / 2): 1, 2, 4 or 8
-    hipError_t (*col_u8)(hipStream_t, const float* planes, uint8_t* dst, int rows, int cols, int pad,
+    // C = complex lines per workgroup (strip width / 2): 2 or 4
+    hipError_t (*col_u8)(hipStream_t, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes,
                          const float2* tw, const float* mperm, int C);
     size_t (*col_lds_bytes)(int rows, int C);
 };
@@ -66,27 +111,48 @@ __device__ __forceinline__ void fk_inner_pass(float2* z, int zs, const float2* t
 {
     constexpr int R = PL::R[I], m = PL::m(I), nb = PL::nb(I), total = nb * C;
     constexpr int off = PL::tw_off(I) - PL::lds_tw_begin();
-#pragma unroll 1
+    FK_UNROLL(FK_INNER_UNROLL)
     for (int g = threadIdx.x; g < total; g += T) {
         const int c = g / nb, b = g - c * nb;
         const int blk = b / m, j = b - blk * m;
         const int base = blk * (R * m) + j;
         float2* zc = z + c * zs;
+        // Radices up to FK_HOIST_MAX_R: issue every LDS read (data and twiddles) before the first
+        // use (one latency, not R).  Larger radices would spill, there the twiddles are read
+        // where they are used.
         float2 v[R];
-        if constexpr (!INV) {
 #pragma unroll
-            for (int k = 0; k < R; ++k) v[k] = zc[phys(base + k * m)];
-            Bfly<R, false>::run(v);
-            zc[phys(base)] = v[0];
+        for (int k = 0; k < R; ++k) v[k] = zc[PL::at(base + k * m)];
+        if constexpr (R <= FK_HOIST_MAX_R) {
+            float2 w[R];
 #pragma unroll
-            for (int q = 1; q < R; ++q) zc[phys(base + q * m)] = cmul(v[q], twl[off + (q - 1) * m + j]);
+            for (int q = 1; q < R; ++q) w[q] = twl[off + (q - 1) * m + j];
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!INV) {
+                Bfly<R, false>::run(v);
+                zc[PL::at(base)] = v[0];
+#pragma unroll
+                for (int q = 1; q < R; ++q) zc[PL::at(base + q * m)] = cmul(v[q], w[q]);
+            } else {
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], w[q]);
+                Bfly<R, true>::run(v);
+#pragma unroll
+                for (int k = 0; k < R; ++k) zc[PL::at(base + k * m)] = v[k];
+            }
         } else {
-            v[0] = zc[phys(base)];
+            if constexpr (!INV) {
+                Bfly<R, false>::run(v);
+                zc[PL::at(base)] = v[0];
 #pragma unroll
-            for (int q = 1; q < R; ++q) v[q] = cmulc(zc[phys(base + q * m)], twl[off + (q - 1) * m + j]);
-            Bfly<R, true>::run(v);
+                for (int q = 1; q < R; ++q) zc[PL::at(base + q * m)] = cmul(v[q], twl[off + (q - 1) * m + j]);
+            } else {
 #pragma unroll
-            for (int k = 0; k < R; ++k) zc[phys(base + k * m)] = v[k];
+                for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], twl[off + (q - 1) * m + j]);
+                Bfly<R, true>::run(v);
+#pragma unroll
+                for (int k = 0; k < R; ++k) zc[PL::at(base + k * m)] = v[k];
+            }
         }
     }
 }
@@ -130,13 +196,13 @@ template <class PL, int T, int C> struct MidRegs {
                     float2* zc = z + c * zs;
                     float2 v[R];
 #pragma unroll
-                    for (int k = 0; k < R; ++k) v[k] = zc[phys(b * R + k)];
+                    for (int k = 0; k < R; ++k) v[k] = zc[PL::at(b * R + k)];
                     Bfly<R, false>::run(v);
 #pragma unroll
                     for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mm[it][q]);
                     Bfly<R, true>::run(v);
 #pragma unroll
-                    for (int k = 0; k < R; ++k) zc[phys(b * R + k)] = v[k];
+                    for (int k = 0; k < R; ++k) zc[PL::at(b * R + k)] = v[k];
                 }
             }
         }
@@ -145,22 +211,26 @@ template <class PL, int T, int C> struct MidRegs {
 
 // the same fused middle pass flattened over (line, butterfly), multipliers read from LDS
 template <class PL, int T, int C>
-__device__ __forceinline__ void fk_mid_lds(float2* z, int zs, const float* mpl)
+__device__ __forceinline__ void fk_mid_lds(float2* z, int zs, const float* __restrict__ mpl)
 {
     constexpr int R = PL::R[PL::P - 1], nb = PL::nb(PL::P - 1), total = nb * C;
-#pragma unroll 1
+    FK_UNROLL(FK_INNER_UNROLL)
     for (int g = threadIdx.x; g < total; g += T) {
         const int c = g / nb, b = g - c * nb;
         float2* zc = z + c * zs;
         float2 v[R];
+        float mm[R];
 #pragma unroll
-        for (int k = 0; k < R; ++k) v[k] = zc[phys(b * R + k)];
+        for (int k = 0; k < R; ++k) v[k] = zc[PL::at(b * R + k)];
+#pragma unroll
+        for (int q = 0; q < R; ++q) mm[q] = mpl[b * R + q];
+        if constexpr (R <= FK_HOIST_MAX_R) __builtin_amdgcn_sched_barrier(0);
         Bfly<R, false>::run(v);
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mpl[b * R + q]);
+        for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mm[q]);
         Bfly<R, true>::run(v);
 #pragma unroll
-        for (int k = 0; k < R; ++k) zc[phys(b * R + k)] = v[k];
+        for (int k = 0; k < R; ++k) zc[PL::at(b * R + k)] = v[k];
     }
 }
 
@@ -185,8 +255,8 @@ template <class PL, int T> struct Pass0Regs {
 // row pass
 // ======================================================================================
 template <class PL, int T, int CH>
-__global__ __launch_bounds__(T, 3) void fast_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ planes,
-                                                     int rows, int cols, int pad, int npairs,
+__global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ planes,
+                                                     int rows, int cols, int pad, int npairs, int nunits,
                                                      const float2* __restrict__ tw, const float* __restrict__ mperm)
 {
     static_assert(PL::valid(), "radices do not multiply to N");
@@ -194,21 +264,42 @@ __global__ __launch_bounds__(T, 3) void fast_rowpass_u8(const uint8_t* __restric
     constexpr int R0 = PL::R[0], m0 = PL::m(0);
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* z = reinterpret_cast<float2*>(smem);
-    float2* twl = z + line_stride(N);
+    float2* twl = z + PL::zs();
+    const uint8_t* const src0 = src;
+    float* const planes0 = planes;
     float* mpl = reinterpret_cast<float*>(twl + ((PL::lds_tw_count() + 1) & ~1));
 
+#ifdef FK_STAMPS
+    unsigned long long st_acc[kStampSlots] = {};
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
     Pass0Regs<PL, T> p0;
     p0.load(tw, threadIdx.x);
     for (int i = threadIdx.x; i < PL::lds_tw_count(); i += T) twl[i] = tw[PL::lds_tw_begin() + i];
+#if FK_ROW_MID_GLOBAL
+    (void)mpl;
+    const float* mid_tab = mperm;
+#else
     for (int i = threadIdx.x; i < N; i += T) mpl[i] = mperm[i];
+    const float* mid_tab = mpl;
+#endif
 
-    for (int pair = fk_xcd_contiguous(blockIdx.x, gridDim.x); pair < npairs; pair += gridDim.x) {
+    // persistent workgroup: a contiguous run of (frame, row pair) units, so the register-resident
+    // tables above are loaded once for many lines
+    const int u_begin = static_cast<int>(static_cast<long long>(blockIdx.x) * nunits / gridDim.x);
+    const int u_end = static_cast<int>(static_cast<long long>(blockIdx.x + 1) * nunits / gridDim.x);
+    for (int u = u_begin; u < u_end; ++u) {
+        const int f = u / npairs, pair = u - f * npairs;
+        src = src0 + static_cast<size_t>(f) * rows * cols * CH;
+        planes = planes0 + static_cast<size_t>(f) * rows * cols * CH;
         const int r0 = 2 * pair;
         const bool two = r0 + 1 < rows;
         const uint8_t* row_a = src + static_cast<size_t>(r0) * cols * CH;
         const uint8_t* row_b = row_a + (two ? static_cast<size_t>(cols) * CH : 0);
         for (int c = 0; c < CH; ++c) {
+            FK_STAMP(0);       // prologue (first line) / loop overhead
             __syncthreads();   // previous line's readers are done with z (and twl is visible)
+            FK_STAMP(1);       // barrier
             // ---- pass 0: global u8 -> butterfly -> twiddle -> LDS
 #pragma unroll
             for (int it = 0; it < Pass0Regs<PL, T>::IT; ++it) {
@@ -223,24 +314,35 @@ __global__ __launch_bounds__(T, 3) void fast_rowpass_u8(const uint8_t* __restric
                         const int x = fk_reflect_src(j + k * m0, pad, cols);
                         ok[k] = x >= 0;
                         const int xi = (x >= 0 ? x : 0) * CH + c;
+#ifdef FK_ABL_NOLOAD    // ablation build: no global reads (timing only, results are wrong)
+                        pa[k] = static_cast<uint8_t>(xi); pb[k] = static_cast<uint8_t>(xi + j);
+#else
                         pa[k] = row_a[xi];
                         pb[k] = row_b[xi];
+#endif
                     }
                     float2 v[R0];
 #pragma unroll
                     for (int k = 0; k < R0; ++k)
                         v[k] = make_float2(ok[k] ? static_cast<float>(pa[k]) : 0.f, (ok[k] && two) ? static_cast<float>(pb[k]) : 0.f);
                     Bfly<R0, false>::run(v);
-                    z[phys(j)] = v[0];
+                    z[PL::at(j)] = v[0];
 #pragma unroll
-                    for (int q = 1; q < R0; ++q) z[phys(j + q * m0)] = cmul(v[q], p0.w[it][q]);
+                    for (int q = 1; q < R0; ++q) z[PL::at(j + q * m0)] = cmul(v[q], p0.w[it][q]);
                 }
             }
+            FK_STAMP(2);       // pass 0 incl. global loads
             __syncthreads();
+            FK_STAMP(3);       // barrier
+#ifndef FK_ABL_NOMIDDLE  // ablation build: only pass 0 and its inverse
             fk_inner_passes<PL, 1, 1, T, false>(z, 0, twl);
-            fk_mid_lds<PL, T, 1>(z, 0, mpl);
+            FK_STAMP(4);       // forward inner passes + their barriers
+            fk_mid_lds<PL, T, 1>(z, 0, mid_tab);
             __syncthreads();
+            FK_STAMP(5);       // fused middle + barrier
             fk_inner_passes<PL, P - 2, 1, T, true>(z, 0, twl);
+            FK_STAMP(6);       // inverse inner passes + barriers
+#endif
             // ---- inverse pass 0: LDS -> conj twiddle -> butterfly -> cropped float rows
             float* out_a = planes + (static_cast<size_t>(c) * rows + r0) * cols;
             float* out_b = out_a + cols;
@@ -249,22 +351,33 @@ __global__ __launch_bounds__(T, 3) void fast_rowpass_u8(const uint8_t* __restric
                 const int j = threadIdx.x + T * it;
                 if (j < m0) {
                     float2 v[R0];
-                    v[0] = z[phys(j)];
+                    v[0] = z[PL::at(j)];
 #pragma unroll
-                    for (int q = 1; q < R0; ++q) v[q] = cmulc(z[phys(j + q * m0)], p0.w[it][q]);
+                    for (int q = 1; q < R0; ++q) v[q] = cmulc(z[PL::at(j + q * m0)], p0.w[it][q]);
                     Bfly<R0, true>::run(v);
 #pragma unroll
                     for (int k = 0; k < R0; ++k) {
                         const int x = j + k * m0 - pad;
+#ifdef FK_ABL_NOSTORE   // ablation build: no global writes, values kept alive
+                        asm volatile("" ::"v"(v[k].x), "v"(v[k].y), "v"(x));
+#else
                         if (x >= 0 && x < cols) {
                             out_a[x] = v[k].x;
                             if (two) out_b[x] = v[k].y;
                         }
+#endif
                     }
                 }
             }
+            FK_STAMP(7);       // inverse pass 0 + global stores
         }
     }
+#ifdef FK_STAMPS
+    if (threadIdx.x == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(mperm) + N) + static_cast<size_t>(blockIdx.x) * kStampSlots;
+        for (int i = 0; i < kStampSlots; ++i) o[i] = st_acc[i];
+    }
+#endif
 }
 
 // ======================================================================================
@@ -272,18 +385,20 @@ __global__ __launch_bounds__(T, 3) void fast_rowpass_u8(const uint8_t* __restric
 // ======================================================================================
 template <class PL, int T, int C, int CH>
 __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ planes, uint8_t* __restrict__ dst,
-                                                     int rows, int cols, int pad, int nstrips,
+                                                     int rows, int cols, int pad, int nstrips, int nunits,
                                                      const float2* __restrict__ tw, const float* __restrict__ mperm)
 {
     static_assert(PL::valid(), "radices do not multiply to N");
     constexpr int N = PL::N, P = PL::P, G = 2 * C;
+    const float* const planes0 = planes;
+    uint8_t* const dst0 = dst;
     constexpr int R0 = PL::R[0], m0 = PL::m(0);
     // pass 0: K thread groups of m0 butterflies, group gi takes lines gi, gi+K, ...
     constexpr int IT0 = Pass0Regs<PL, T>::IT;
     constexpr int K = IT0 == 1 ? (T / m0 > C ? C : T / m0) : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* z = reinterpret_cast<float2*>(smem);
-    constexpr int zs = line_stride(N);
+    constexpr int zs = PL::zs();
     float2* twl = z + C * zs;
     float* mpl = reinterpret_cast<float*>(twl + ((PL::lds_tw_count() + 1) & ~1));         // N multipliers, position order
     uint8_t* stage = reinterpret_cast<uint8_t*>(mpl + N);                                  // [rows][G*CH] bytes
@@ -296,7 +411,15 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
     for (int i = threadIdx.x; i < PL::lds_tw_count(); i += T) twl[i] = tw[PL::lds_tw_begin() + i];
     for (int i = threadIdx.x; i < N; i += T) mpl[i] = mperm[i];
 
-    for (int strip = fk_xcd_contiguous(blockIdx.x, gridDim.x); strip < nstrips; strip += gridDim.x) {
+    // persistent workgroup over a contiguous run of (frame, strip) units; workgroups that share
+    // an XCD get neighbouring runs (neighbouring strips share 128-byte lines in that XCD's L2)
+    const int vb = fk_xcd_contiguous(blockIdx.x, gridDim.x);
+    const int u_begin = static_cast<int>(static_cast<long long>(vb) * nunits / gridDim.x);
+    const int u_end = static_cast<int>(static_cast<long long>(vb + 1) * nunits / gridDim.x);
+    for (int u = u_begin; u < u_end; ++u) {
+        const int f = u / nstrips, strip = u - f * nstrips;
+        planes = planes0 + static_cast<size_t>(f) * rows * cols * CH;
+        dst = dst0 + static_cast<size_t>(f) * rows * cols * CH;
         const int x0 = strip * G;
         for (int ch = 0; ch < CH; ++ch) {
             const float* plane = planes + static_cast<size_t>(ch) * rows * cols;
@@ -306,12 +429,12 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
             if (full) {
                 // unconditional 8-byte loads (clamped row, masked value): the unrolled loop keeps
                 // several independent loads in flight per thread
-#pragma unroll 8
+                FK_UNROLL(FK_GATHER_UNROLL)
                 for (int idx = threadIdx.x; idx < N * C; idx += T) {
                     const int p = idx / C, l = idx - p * C;
                     const int r = fk_reflect_src(p, pad, rows);
                     const float2 t = *reinterpret_cast<const float2*>(plane + static_cast<size_t>(r >= 0 ? r : 0) * cols + x0 + 2 * l);
-                    z[l * zs + phys(p)] = r >= 0 ? t : make_float2(0.f, 0.f);
+                    z[l * zs + PL::at(p)] = r >= 0 ? t : make_float2(0.f, 0.f);
                 }
             } else {
 #pragma unroll 4
@@ -321,7 +444,7 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
                     const int col = x0 + 2 * l;
                     const float* s = plane + static_cast<size_t>(r >= 0 ? r : 0) * cols;
                     const float a = s[col < cols ? col : cols - 1], b = s[col + 1 < cols ? col + 1 : cols - 1];
-                    z[l * zs + phys(p)] = make_float2((r >= 0 && col < cols) ? a : 0.f, (r >= 0 && col + 1 < cols) ? b : 0.f);
+                    z[l * zs + PL::at(p)] = make_float2((r >= 0 && col < cols) ? a : 0.f, (r >= 0 && col + 1 < cols) ? b : 0.f);
                 }
             }
             __syncthreads();
@@ -336,11 +459,11 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
                             float2* zc = z + c * zs;
                             float2 v[R0];
 #pragma unroll
-                            for (int k = 0; k < R0; ++k) v[k] = zc[phys(j + k * m0)];
+                            for (int k = 0; k < R0; ++k) v[k] = zc[PL::at(j + k * m0)];
                             Bfly<R0, false>::run(v);
-                            zc[phys(j)] = v[0];
+                            zc[PL::at(j)] = v[0];
 #pragma unroll
-                            for (int q = 1; q < R0; ++q) zc[phys(j + q * m0)] = cmul(v[q], p0.w[it][q]);
+                            for (int q = 1; q < R0; ++q) zc[PL::at(j + q * m0)] = cmul(v[q], p0.w[it][q]);
                         }
                     }
                 }
@@ -360,9 +483,9 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
                         for (int c = gi; c < C; c += K) {
                             const float2* zc = z + c * zs;
                             float2 v[R0];
-                            v[0] = zc[phys(j)];
+                            v[0] = zc[PL::at(j)];
 #pragma unroll
-                            for (int q = 1; q < R0; ++q) v[q] = cmulc(zc[phys(j + q * m0)], p0.w[it][q]);
+                            for (int q = 1; q < R0; ++q) v[q] = cmulc(zc[PL::at(j + q * m0)], p0.w[it][q]);
                             Bfly<R0, true>::run(v);
 #pragma unroll
                             for (int k = 0; k < R0; ++k) {
@@ -402,16 +525,26 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
 // ---- launchers ---------------------------------------------------------------------------
 template <class PL> size_t fk_row_lds()
 {
-    return (static_cast<size_t>(line_stride(PL::N)) + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) + static_cast<size_t>(PL::N) * sizeof(float);
+    return (static_cast<size_t>(PL::zs()) + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) +
+           (FK_ROW_MID_GLOBAL ? 0 : static_cast<size_t>(PL::N) * sizeof(float));
 }
 
 template <class PL, int C> size_t fk_col_lds(int rows)
 {
-    return (static_cast<size_t>(C) * line_stride(PL::N) + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) +
+    return (static_cast<size_t>(C) * PL::zs() + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) +
            static_cast<size_t>(PL::N) * sizeof(float) + static_cast<size_t>(rows) * 2 * C * 3 + 16;
 }
 
-template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uint8_t* src, float* planes, int rows, int cols, int pad,
+// grid for `units` equal work items on `slots` resident workgroups: as many rounds as needed, all equally full
+inline int fk_balanced_grid(int units, int slots)
+{
+    if (units <= slots) return units;
+    const int rounds = (units + slots - 1) / slots;
+    return (units + rounds - 1) / rounds;
+}
+constexpr int kNumCUs = 256;
+
+template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uint8_t* src, float* planes, int rows, int cols, int pad, int nframes,
                                                const float2* tw, const float* mperm)
 {
     const size_t lds = fk_row_lds<PL>();
@@ -420,12 +553,18 @@ template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uin
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
     }
-    const int npairs = (rows + 1) / 2;
-    hipLaunchKernelGGL(kern, dim3(npairs), dim3(T), lds, st, src, planes, rows, cols, pad, npairs, tw, mperm);
+    const int npairs = (rows + 1) / 2, nunits = npairs * nframes;
+    // resident workgroups per CU: LDS, and FK_ROW_WAVES_PER_SIMD waves on each of the 4 SIMDs
+    int per_cu = static_cast<int>((160 * 1024) / lds);
+    const int by_waves = FK_ROW_WAVES_PER_SIMD * 4 / ((T + 63) / 64);
+    if (per_cu > by_waves) per_cu = by_waves;
+    if (per_cu < 1) per_cu = 1;
+    const int grid = fk_balanced_grid(nunits, kNumCUs * per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, src, planes, rows, cols, pad, npairs, nunits, tw, mperm);
     return hipGetLastError();
 }
 
-template <class PL, int T, int C> hipError_t fk_launch_col_u8_c(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad,
+template <class PL, int T, int C> hipError_t fk_launch_col_u8_c(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes,
                                                          const float2* tw, const float* mperm)
 {
     const size_t lds = fk_col_lds<PL, C>(rows);
@@ -434,17 +573,21 @@ template <class PL, int T, int C> hipError_t fk_launch_col_u8_c(hipStream_t st, 
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
     }
-    const int nstrips = (cols + 2 * C - 1) / (2 * C);
-    hipLaunchKernelGGL(kern, dim3(nstrips), dim3(T), lds, st, planes, dst, rows, cols, pad, nstrips, tw, mperm);
+    const int nstrips = (cols + 2 * C - 1) / (2 * C), nunits = nstrips * nframes;
+    int per_cu = static_cast<int>((160 * 1024) / lds);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu * ((T + 63) / 64) > 32) per_cu = 32 / ((T + 63) / 64);
+    const int grid = fk_balanced_grid(nunits, kNumCUs * per_cu);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, planes, dst, rows, cols, pad, nstrips, nunits, tw, mperm);
     return hipGetLastError();
 }
 
-template <class PL, int T> hipError_t fk_launch_col_u8(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad,
+template <class PL, int T> hipError_t fk_launch_col_u8(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes,
                                                const float2* tw, const float* mperm, int C)
 {
     switch (C) {
-    case 4: return fk_launch_col_u8_c<PL, T, 4>(st, planes, dst, rows, cols, pad, tw, mperm);
-    case 2: return fk_launch_col_u8_c<PL, T, 2>(st, planes, dst, rows, cols, pad, tw, mperm);
+    case 4: return fk_launch_col_u8_c<PL, T, 4>(st, planes, dst, rows, cols, pad, nframes, tw, mperm);
+    case 2: return fk_launch_col_u8_c<PL, T, 2>(st, planes, dst, rows, cols, pad, nframes, tw, mperm);
     default: return hipErrorInvalidValue;
     }
 }
@@ -472,12 +615,12 @@ template <class PL, int TROW, int TCOL> FastEntry fk_make_entry()
 
 }  // namespace blur_amd
 
-// one translation unit per FFT length: BLUR_FAST_INSTANCE(4000, TROW, TCOL, 16, 10, 25)
-#define BLUR_FAST_INSTANCE(NN, TROW, TCOL, ...)                                                            \
+// one translation unit per FFT length: BLUR_FAST_INSTANCE(4000, PAD, TROW, TCOL, 16, 10, 25)
+#define BLUR_FAST_INSTANCE(NN, PAD, TROW, TCOL, ...)                                                            \
     namespace blur_amd {                                                                         \
     const FastEntry* fast_entry_##NN()                                                           \
     {                                                                                            \
-        static const FastEntry e = fk_make_entry<StaticPlan<NN, __VA_ARGS__>, TROW, TCOL>();               \
+        static const FastEntry e = fk_make_entry<StaticPlan<NN, PAD, __VA_ARGS__>, TROW, TCOL>();               \
         return &e;                                                                               \
     }                                                                                            \
     }

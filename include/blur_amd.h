@@ -47,6 +47,9 @@ typedef struct blur_opts {
     int nyquist_quirk;
     /* columns per workgroup of the column pass (0 = auto: 8 or less as LDS allows) */
     int col_group;
+    /* reserved[0] = 1: use the run-time-planned kernels even where a compile-time specialised
+       one exists (tests); reserved[1] > 0: frames per launch pair of the batch entry point
+       (0 = auto: as many as keep the float intermediate within the Infinity Cache) */
     int reserved[6];
 } blur_opts;
 
@@ -94,10 +97,11 @@ const char* blur_last_error(const blur_ctx* ctx);
 
 /* Per-kernel timing with HIP events on the ctx's stream.  While enabled, every launch
    of the row-pass and column-pass kernels is bracketed by events; blur_ctx_timing()
-   synchronises, then returns the summed milliseconds and launch counts since the last
-   reset:  out_ms[0]=row pass, out_ms[1]=column pass; out_launches likewise. */
+   synchronises, then returns the summed milliseconds, the launch counts and the number of
+   frames those launches covered (a batch launch processes several frames) since the last
+   reset:  out_ms[0]=row pass, out_ms[1]=column pass; the others likewise. */
 int blur_ctx_timing_enable(blur_ctx* ctx, int on);
-int blur_ctx_timing(blur_ctx* ctx, double out_ms[2], int out_launches[2], int reset);
+int blur_ctx_timing(blur_ctx* ctx, double out_ms[2], int out_launches[2], int out_frames[2], int reset);
 
 /* ---- the hot path: pffft_(image, sigma)             Source.cpp:429-570 ------------- */
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/build_variant.sh NAME "N TROW TCOL R,R,R" ...   [env: VFLAGS="-D..."]
+# tools/build_variant.sh NAME "N PAD TROW TCOL R,R,R" ...   [env: VFLAGS="-D..."]
 # Builds blur_algorithms_amd/variants/libblur_amd_NAME.so with the given compile-time plans
 # (any length not listed keeps the plan of csrc/fast_N.hip).  For A/B runs on the GPU box:
 #   BLUR_AMD_LIB=blur_algorithms_amd/variants/libblur_amd_NAME.so python tools/kbench.py
@@ -13,7 +13,7 @@ for f in $CS/fast_*.hip; do cp $f $BD/; done
 for spec in "$@"; do set -- $spec
 cat > $BD/fast_$1.hip <<EOT
 #include "fast_kernels.hpp"
-BLUR_FAST_INSTANCE($1, $2, $3, $4)
+BLUR_FAST_INSTANCE($1, $2, $3, $4, $5)
 EOT
 done
 pids=""
