@@ -11,9 +11,11 @@ FRAMES frames per GPU per step).  Rank 0 prints ONE JSON line.
 
 Extra objects in that line:
   roofline     -- for the slower of the two kernels: algorithmic bytes per launch
-                  (15 B/px: 3 u8 in + 12 f32 out for the row pass, 12 + 3 for the column
-                  pass) / its average launch duration from HIP events recorded
-                  on the launch stream inside the timed region; peak 8 TB/s HBM3E.
+                  (15 B/px x the pixels of the frames that launch covers: 3 u8 in + 12 f32 out
+                  for the row pass, 12 + 3 for the column pass) / its average
+                  launch duration from HIP events recorded on the launch stream inside the timed
+                  region; peak 8 TB/s HBM3E; traffic = HBM bytes per launch from the rocprofv3
+                  PMC passes committed under profiles/ (null until collected).
   cpu_baseline -- the CPU port of the same path (oracle/blur_oracle.c, float32, OpenMP, same
                   stage structure as the reference; NOT pffft) timed on this host's cores.
 """
@@ -53,6 +55,20 @@ def cpu_baseline(rows, cols, sigma, budget_s=8.0):
     }
 
 
+def pmc_traffic(kernel, frames_per_launch):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate
+    FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied there), or None"""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        t = json.load(open(path))
+        e = t[kernel]
+        if abs(e["frames_per_launch"] - frames_per_launch) > 1e-9:
+            return None
+        return e["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -63,6 +79,7 @@ def main():
     ap.add_argument("--cols", type=int, default=3840)
     ap.add_argument("--sigma", type=float, default=20.0)
     ap.add_argument("--col-group", type=int, default=0)
+    ap.add_argument("--frames-per-launch", type=int, default=0, help="0 = the library's choice")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -91,7 +108,7 @@ def main():
     ctx = B.BlurContext(local)
 
     def step():
-        ctx.pffft_(frames, sigma, out=out, col_group=args.col_group)
+        ctx.pffft_(frames, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch)
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -147,13 +164,16 @@ def main():
         if tm and tm["row_launches"] and tm["col_launches"]:
             row_ms = tm["row_ms"] / tm["row_launches"]
             col_ms = tm["col_ms"] / tm["col_launches"]
-            name, dur = ("colpass_kernel", col_ms) if col_ms >= row_ms else ("rowpass_kernel", row_ms)
-            achieved = ALG_BYTES_PER_PX_KERNEL * px / (dur * 1e-3) / 1e9
+            fpl = tm["row_frames"] / tm["row_launches"]            # frames one launch covers
+            name, dur = ("fast_colpass_u8", col_ms) if col_ms >= row_ms else ("fast_rowpass_u8", row_ms)
+            alg = ALG_BYTES_PER_PX_KERNEL * px * fpl
+            achieved = alg / (dur * 1e-3) / 1e9
             rec["roofline"] = {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "avg_launch_ms": {"rowpass_kernel": round(row_ms, 4), "colpass_kernel": round(col_ms, 4)},
-                "alg_bytes_per_launch": ALG_BYTES_PER_PX_KERNEL * px,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name, fpl),
+                "avg_launch_ms": {"fast_rowpass_u8": round(row_ms, 4), "fast_colpass_u8": round(col_ms, 4)},
+                "frames_per_launch": fpl,
+                "alg_bytes_per_launch": alg,
             }
         if world == 1 and not args.no_cpu:
             rec["cpu_baseline"] = cpu_baseline(rows, cols, sigma)

@@ -411,12 +411,16 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
     for (int i = threadIdx.x; i < PL::lds_tw_count(); i += T) twl[i] = tw[PL::lds_tw_begin() + i];
     for (int i = threadIdx.x; i < N; i += T) mpl[i] = mperm[i];
 
-    // persistent workgroup over a contiguous run of (frame, strip) units; workgroups that share
-    // an XCD get neighbouring runs (neighbouring strips share 128-byte lines in that XCD's L2)
-    const int vb = fk_xcd_contiguous(blockIdx.x, gridDim.x);
-    const int u_begin = static_cast<int>(static_cast<long long>(vb) * nunits / gridDim.x);
-    const int u_end = static_cast<int>(static_cast<long long>(vb + 1) * nunits / gridDim.x);
-    for (int u = u_begin; u < u_end; ++u) {
+    // Persistent workgroup.  Workgroups b, b+8, b+16, ... share an XCD and its L2 (dispatch is
+    // round-robin over the 8 XCDs: speed only, never correctness).  Each XCD gets one contiguous
+    // run of (frame, strip) units and its workgroups walk it INTERLEAVED, so that at any moment
+    // they sit on neighbouring strips: a 128-byte line of the float planes (4 strips wide) and of
+    // the u8 output (5.3 strips wide) is then touched by all its users while it is still in L2.
+    const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3;
+    const int wg_in_xcd = (static_cast<int>(gridDim.x) - xcd + 7) >> 3;
+    const int u_begin = static_cast<int>(static_cast<long long>(xcd) * nunits / 8);
+    const int u_end = static_cast<int>(static_cast<long long>(xcd + 1) * nunits / 8);
+    for (int u = u_begin + lane_in_xcd; u < u_end; u += wg_in_xcd) {
         const int f = u / nstrips, strip = u - f * nstrips;
         planes = planes0 + static_cast<size_t>(f) * rows * cols * CH;
         dst = dst0 + static_cast<size_t>(f) * rows * cols * CH;

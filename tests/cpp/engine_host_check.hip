@@ -3,12 +3,15 @@
 // exact butterfly / twiddle / permuted-multiplier code the kernels run can be checked
 // without a GPU: for every pass, loop tid over a pretend workgroup (the loop end plays the
 // role of __syncthreads()).  Compared against a float64 O(N^2) circular convolution.
-// Usage: engine_host_check N [N...]   exit code 0 = all within tolerance.
+// Usage: engine_host_check N [N...] [-r R0,R1,..]   exit code 0 = all within tolerance.
+// (-r: explicit radix sequence; build with -DBLUR_ENGINE_ALL_RADICES for the large composites.)
 #include <cmath>
 #include <complex>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <random>
+#include <string>
 #include <vector>
 
 #include "../../blur_algorithms_amd/csrc/fft_engine.hpp"
@@ -16,10 +19,11 @@
 
 using namespace blur_amd;
 
-template <int C> static double check(int n, double sigma, bool quirk)
+template <int C> static double check(int n, double sigma, bool quirk, const std::vector<int>& radices = {})
 {
     FftPlan plan;
-    if (!make_plan(n, plan)) { std::printf("N=%d: no plan\n", n); return 1e9; }
+    const bool ok = radices.empty() ? make_plan(n, plan) : make_plan_radices(n, radices.data(), (int)radices.size(), plan);
+    if (!ok) { std::printf("N=%d: no plan\n", n); return 1e9; }
     DevPlan dp{};
     dp.n = n; dp.npass = plan.npass;
     for (int i = 0; i < plan.npass; ++i) { dp.radix[i] = plan.radix[i]; dp.m[i] = plan.m[i]; dp.tw_off[i] = plan.tw_off[i]; }
@@ -83,6 +87,14 @@ int main(int argc, char** argv)
 {
     int bad = 0;
     for (int a = 1; a < argc; ++a) {
+        if (std::string(argv[a]) == "-r" && a + 1 < argc) {      // explicit radix list: -r 16,10,25
+            std::vector<int> r;
+            int n = 1;
+            for (char* t = std::strtok(argv[++a], ","); t; t = std::strtok(nullptr, ",")) { r.push_back(std::atoi(t)); n *= r.back(); }
+            if (check<1>(n, 3.0, true, r) > 2e-6) ++bad;
+            if (check<3>(n, 5.0, false, r) > 2e-6) ++bad;
+            continue;
+        }
         const int n = std::atoi(argv[a]);
         if (check<1>(n, 3.0, true) > 2e-6) ++bad;
         if (check<3>(n, 5.0, false) > 2e-6) ++bad;

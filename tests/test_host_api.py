@@ -1,0 +1,98 @@
+"""CPU tests of the product's host side: the C-ABI library loads and exports every symbol the
+header declares, the host-side sizing / kernel / plan arithmetic equals the oracle (and the
+reference vectors), the device FFT arithmetic run on the CPU equals a float64 DFT, and the C++
+header with the reference's names compiles and behaves.  No GPU compute is called here."""
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import blur_algorithms_amd as B
+from blur_algorithms_amd import _lib
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REFV = np.load(os.path.join(ROOT, "tests", "golden", "ref_host_functions.npz"))
+HIPCC = "/opt/rocm/bin/hipcc"
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "blur_amd.h")).read()
+    declared = set(re.findall(r"\b(blur_[a-z0-9_]+)\s*\(", header)) - {"blur_opts", "blur_ctx"}
+    assert len(declared) >= 25
+    lib = ctypes.CDLL(B.LIB_PATH)
+    missing = [s for s in sorted(declared) if not hasattr(lib, s)]
+    assert not missing, missing
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)     # the Python binding covers the whole header
+
+
+def test_no_gpu_means_a_loud_error_not_a_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("this process has a GPU")
+    with pytest.raises(B.BlurError) as e:
+        B.BlurContext(0)
+    assert e.value.code == 3
+
+
+def test_host_sizing_equals_reference_vectors():
+    got = [B.gaussian_window(float(s), int(m)) for s, m in zip(REFV["gw_sigma"], REFV["gw_maxw"])]
+    assert got == REFV["gw_width"].tolist()
+    n = REFV["size_n"]
+    assert [B.isValidSize(int(i)) for i in n] == REFV["size_valid"].tolist()
+    assert [B.nearestTransformSize(int(i)) for i in n] == REFV["size_nearest"].tolist()
+    for i, (s, w, f) in enumerate(REFV["gk_cases"]):
+        assert np.array_equal(B.getGaussian(float(s), int(w), int(f)), REFV["gk_%d" % i])
+
+
+def test_host_sizing_and_multipliers_equal_oracle():
+    for rows, cols, s in [(512, 512, 5), (1080, 1920, 20), (2160, 3840, 50), (2160, 3840, 20), (4320, 7680, 20), (101, 203, 4)]:
+        assert B.pffft_sizing(rows, cols, s) == O.pffft_sizing(rows, cols, s)
+    for s, k, n in [(5, 31, 576), (20, 131, 4000), (20, 131, 2304), (50, 331, 4320), (3, 19, 128)]:
+        assert np.array_equal(B.kernel_multipliers(s, k, n), O.kernel_multipliers(s, k, n))
+
+
+def test_plans_cover_every_valid_length():
+    supported = {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 25}
+    for n in range(32, 13000, 32):
+        if not B.isValidSize(n):
+            continue
+        r = B.fft_plan_radices(n)
+        assert r and int(np.prod(r)) == n and set(r) <= supported, (n, r)
+    assert B.fft_plan_radices(7 * 32) == []
+    # the BASELINE lengths use the three/four-pass compile-time plans
+    assert len(B.fft_plan_radices(4000)) <= 4 and len(B.fft_plan_radices(2304)) == 3
+
+
+@pytest.fixture(scope="module")
+def engine_host_check(tmp_path_factory):
+    exe = str(tmp_path_factory.mktemp("cpp") / "engine_host_check")
+    subprocess.check_call([HIPCC, "--cuda-host-only", "-O2", "-std=c++17", "-DBLUR_ENGINE_ALL_RADICES",
+                           os.path.join(ROOT, "tests", "cpp", "engine_host_check.hip"),
+                           os.path.join(ROOT, "blur_algorithms_amd", "csrc", "host_math.cpp"), "-o", exe],
+                          stderr=subprocess.DEVNULL)
+    return exe
+
+
+def test_device_fft_arithmetic_on_cpu(engine_host_check):
+    """the __host__ __device__ butterflies / passes / permuted multipliers of fft_engine.hpp, driven
+    thread by thread on the CPU, against a float64 O(N^2) circular convolution"""
+    out = subprocess.run([engine_host_check, "32", "96", "160", "288", "480", "576", "800", "1280"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    # explicit radix lists: the compile-time plans' butterflies (25, 18, 15, 12, 20)
+    out = subprocess.run([engine_host_check, "-r", "16,10,25", "-r", "16,18,15", "-r", "20,20,10", "-r", "12,12,16", "-r", "16,10,5,5"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+def test_cpp_header_with_reference_names():
+    exe = os.path.join(ROOT, "tests", "cpp", "surface_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fopenmp", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "surface_check.cpp"),
+                           "-L" + os.path.dirname(B.LIB_PATH), "-lblur_amd", "-Wl,-rpath," + os.path.dirname(B.LIB_PATH),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe, "host"], capture_output=True, text=True)
+    assert out.returncode == 0 and "host ok" in out.stdout, out.stdout + out.stderr
