@@ -93,13 +93,14 @@ class BlurContext:
         if rc:
             raise BlurError(rc, self._lib.blur_last_error(self._h).decode())
 
-    def _opts(self, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0):
+    def _opts(self, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0, row_major_planes=False):
         o = BlurOpts()
         self._lib.blur_opts_default(C.byref(o))
         o.nyquist_quirk = 1 if nyquist_quirk else 0
         o.col_group = int(col_group)
         o.reserved[0] = 1 if force_generic else 0   # tests: run the run-time-planned kernels even where a specialised one exists
         o.reserved[1] = int(frames_per_launch)
+        o.reserved[2] = 1 if row_major_planes else 0
         return o
 
     def use_torch_stream(self):
@@ -123,13 +124,14 @@ class BlurContext:
         return dict(row_ms=ms[0], col_ms=ms[1], row_launches=n[0], col_launches=n[1], row_frames=fr[0], col_frames=fr[1])
 
     # -- pffft_(image, sigma): Source.cpp:429-570 -----------------------------------------
-    def pffft_(self, image, sigma, out=None, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0):
+    def pffft_(self, image, sigma, out=None, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0,
+               row_major_planes=False):
         """Gaussian blur of a BGR/RGB uint8 image [rows, cols, 3] or a batch [n, rows, cols, 3].
 
         torch CUDA tensor: asynchronous on torch's current stream, returns `out`
         (default: in place, like the reference).  numpy array: host round trip, returns a new array.
         """
-        o = self._opts(nyquist_quirk, col_group, force_generic, frames_per_launch)
+        o = self._opts(nyquist_quirk, col_group, force_generic, frames_per_launch, row_major_planes)
         if isinstance(image, np.ndarray):
             a = np.ascontiguousarray(image, np.uint8)
             if a.ndim != 3 or a.shape[2] != 3:

@@ -252,13 +252,14 @@ struct DevicePlan {
     DevPlan dev{};
     float2* d_tw = nullptr;
     const FastEntry* fast = nullptr;   // compile-time specialised kernels for this length, if any
+    int key = 0;
 };
 
 struct blur_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
-    std::map<int, std::unique_ptr<DevicePlan>> plans;   // key: 2*n + (fast ? 1 : 0)
+    std::map<int, std::unique_ptr<DevicePlan>> plans;   // key: 4*n + role (0 generic, 1 specialised row, 2 specialised column)
     // (plan key, ksize, quirk, sigma bits) -> device multiplier table in position order
     std::map<std::tuple<int, int, int, uint64_t>, float*> spectra;
     std::map<int, float*> last_spectrum;   // n -> most recent table (diagnostic stamp read-back)
@@ -291,14 +292,15 @@ static int fail(blur_ctx* ctx, int code, const char* msg)
     return code;
 }
 
-static int get_plan(blur_ctx* ctx, int n, bool want_fast, DevicePlan** out)
+static int get_plan(blur_ctx* ctx, int n, bool want_fast, bool column_role, DevicePlan** out)
 {
-    const FastEntry* fe = want_fast ? find_fast_entry(n) : nullptr;
-    const int key = 2 * n + (fe ? 1 : 0);
+    const FastEntry* fe = want_fast ? find_fast_entry(n, column_role) : nullptr;
+    const int key = 4 * n + (fe ? (column_role ? 2 : 1) : 0);
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end()) { *out = it->second.get(); return BLUR_OK; }
     auto dp = std::make_unique<DevicePlan>();
     dp->fast = fe;
+    dp->key = key;
     const bool ok = fe ? make_plan_radices(n, fe->radix, fe->npass, dp->host) : make_plan(n, dp->host);
     if (!ok) return fail(ctx, BLUR_ERR_UNSUPPORTED, "FFT length is not 2^a 3^b 5^c");
     dp->dev.n = n;
@@ -321,7 +323,7 @@ static int get_spectrum(blur_ctx* ctx, const DevicePlan& plan, double sigma, int
 {
     uint64_t bits;
     std::memcpy(&bits, &sigma, sizeof bits);
-    const auto key = std::make_tuple(2 * plan.dev.n + (plan.fast ? 1 : 0), ksize, quirk ? 1 : 0, bits);
+    const auto key = std::make_tuple(plan.key, ksize, quirk ? 1 : 0, bits);
     auto it = ctx->spectra.find(key);
     if (it != ctx->spectra.end()) { *out = it->second; return BLUR_OK; }
     const int n = plan.dev.n;
@@ -334,7 +336,7 @@ static int get_spectrum(blur_ctx* ctx, const DevicePlan& plan, double sigma, int
     HIP_TRY(ctx, hipMemset(d, 0, sizeof(float) * (n + kStampTailFloats)));
     HIP_TRY(ctx, hipMemcpy(d, mp.data(), sizeof(float) * n, hipMemcpyHostToDevice));
     ctx->spectra[key] = d;
-    ctx->last_spectrum[plan.dev.n] = d;
+    ctx->last_spectrum[plan.key] = d;
     *out = d;
     return BLUR_OK;
 }
@@ -451,6 +453,8 @@ struct Prepared {
     float *m_row = nullptr, *m_col = nullptr;
     int col_group = 0;
     int col_fast_c = 0;     // > 0: complex lines per workgroup of the specialised column kernel
+    int tile_w = 0;         // > 0: both passes specialised, the float intermediate uses the strip layout
+    size_t frame_elems = 0; // floats of intermediate per frame
 };
 
 static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p, bool u8c3 = true)
@@ -466,24 +470,29 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     const bool allow_fast = u8c3 && !(opts && opts->reserved[0] == 1);   // reserved[0] = 1: force the generic kernels (tests)
     // the specialised column kernel needs its strip (C complex lines + pixel stage) to fit in LDS
     if (allow_fast)
-        if (const FastEntry* fe = find_fast_entry(p.sz.n_col)) {
+        if (const FastEntry* fe = find_fast_entry(p.sz.n_col, true)) {
             int C = p.col_group > 0 ? (p.col_group >= 8 ? 4 : 2) : 4;
             while (C >= 2 && fe->col_lds_bytes(rows, C) > kLdsLimit) C /= 2;
             p.col_fast_c = C >= 2 ? C : 0;
         }
-    if (int rc = get_plan(ctx, p.sz.n_row, allow_fast, &p.row)) return rc;
-    if (int rc = get_plan(ctx, p.sz.n_col, allow_fast && p.col_fast_c > 0, &p.col)) return rc;
+    if (int rc = get_plan(ctx, p.sz.n_row, allow_fast, false, &p.row)) return rc;
+    if (int rc = get_plan(ctx, p.sz.n_col, allow_fast && p.col_fast_c > 0, true, &p.col)) return rc;
     if (int rc = get_spectrum(ctx, *p.row, sigma, p.sz.kSize, quirk, &p.m_row)) return rc;
     if (int rc = get_spectrum(ctx, *p.col, sigma, p.sz.kSize, quirk, &p.m_col)) return rc;
+    // strip layout of the intermediate only when both kernels understand it
+    const bool no_tile = opts && opts->reserved[2] == 1;
+    p.tile_w = (p.row->fast && p.col->fast && p.col_fast_c == 4 && !no_tile) ? 8 : 0;
+    p.frame_elems = p.tile_w ? static_cast<size_t>((cols + p.tile_w - 1) / p.tile_w) * p.tile_w * rows * 3
+                             : static_cast<size_t>(rows) * cols * 3;
     return BLUR_OK;
 }
 
 // nframes frames back to back (planes: 3*rows*cols floats per frame)
-static int run_rowpass_u8c3(blur_ctx* ctx, const uint8_t* src, float* planes, int rows, int cols, int nframes, const Prepared& p)
+static int run_rowpass_u8c3(blur_ctx* ctx, const uint8_t* src, float* planes, int rows, int cols, int nframes, const Prepared& p, int tile_w)
 {
     if (p.row->fast) {
         TimedLaunch t(ctx, 0, nframes);
-        HIP_TRY(ctx, p.row->fast->row_u8(ctx->stream, src, planes, rows, cols, p.sz.pad, nframes, p.row->d_tw, p.m_row));
+        HIP_TRY(ctx, p.row->fast->row_u8(ctx->stream, src, planes, rows, cols, p.sz.pad, nframes, tile_w, p.row->d_tw, p.m_row));
         return BLUR_OK;
     }
     const size_t px = static_cast<size_t>(rows) * cols;
@@ -496,7 +505,7 @@ static int run_colpass_u8c3(blur_ctx* ctx, const float* planes, uint8_t* dst, in
 {
     if (p.col->fast) {
         TimedLaunch t(ctx, 1, nframes);
-        HIP_TRY(ctx, p.col->fast->col_u8(ctx->stream, planes, dst, rows, cols, p.sz.pad, nframes, p.col->d_tw, p.m_col, p.col_fast_c));
+        HIP_TRY(ctx, p.col->fast->col_u8(ctx->stream, planes, dst, rows, cols, p.sz.pad, nframes, p.tile_w ? 1 : 0, p.col->d_tw, p.m_col, p.col_fast_c));
         return BLUR_OK;
     }
     const size_t px = static_cast<size_t>(rows) * cols;
@@ -633,16 +642,16 @@ int blur_gaussian_u8c3_batch_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d
     // A few frames per launch pair: enough units to fill every CU evenly and to amortise the
     // per-workgroup table loads, few enough that the 12 B/px float intermediate of the chunk
     // still sits in the 256 MiB Infinity Cache when the column pass reads it back.
-    int chunk = opts && opts->reserved[1] > 0 ? opts->reserved[1] : static_cast<int>((192u << 20) / (px * 3 * sizeof(float)));
+    int chunk = opts && opts->reserved[1] > 0 ? opts->reserved[1] : static_cast<int>((192u << 20) / (p.frame_elems * sizeof(float)));
     if (chunk < 1) chunk = 1;
     if (chunk > nframes) chunk = nframes;
     if (nframes == 0) return BLUR_OK;
-    if (int rc = ensure_work(ctx, px * 3 * sizeof(float) * chunk)) return rc;
+    if (int rc = ensure_work(ctx, p.frame_elems * sizeof(float) * chunk)) return rc;
     for (int f = 0; f < nframes; f += chunk) {
         const int nf = nframes - f < chunk ? nframes - f : chunk;
         const uint8_t* s = d_src + static_cast<size_t>(f) * px * 3;
         uint8_t* d = d_dst + static_cast<size_t>(f) * px * 3;
-        if (int rc = run_rowpass_u8c3(ctx, s, ctx->work, rows, cols, nf, p)) return rc;
+        if (int rc = run_rowpass_u8c3(ctx, s, ctx->work, rows, cols, nf, p, p.tile_w)) return rc;
         if (int rc = run_colpass_u8c3(ctx, ctx->work, d, rows, cols, nf, p)) return rc;
     }
     return BLUR_OK;
@@ -671,7 +680,7 @@ int blur_rowpass_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, float* d_planes, 
     if (!d_src || !d_planes) return fail(ctx, BLUR_ERR_INVALID, "null pointer");
     Prepared p;
     if (int rc = prepare(ctx, rows, cols, sigma, opts, p)) return rc;
-    return run_rowpass_u8c3(ctx, d_src, d_planes, rows, cols, 1, p);
+    return run_rowpass_u8c3(ctx, d_src, d_planes, rows, cols, 1, p, 0);   // always row-major for the caller
 }
 
 int blur_gaussian_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int rows, int cols, double sigma, const blur_opts* opts)
@@ -793,11 +802,12 @@ int blur_fastboxblur_u8_host(blur_ctx* ctx, uint8_t* inout, int w, int h, int ch
     return rc;
 }
 
-/* diagnostic builds (-DFK_STAMPS): copy the stamp tail behind the multiplier table of FFT length n */
-int blur_debug_read_stamps(blur_ctx* ctx, int n, unsigned long long* out, int count)
+/* diagnostic builds (-DFK_STAMPS): copy the stamp tail behind the multiplier table of FFT length n
+   (role 1 = specialised row plan, 2 = specialised column plan) */
+int blur_debug_read_stamps(blur_ctx* ctx, int n, int role, unsigned long long* out, int count)
 {
     if (!ctx || !out) return BLUR_ERR_INVALID;
-    auto it = ctx->last_spectrum.find(n);
+    auto it = ctx->last_spectrum.find(4 * n + role);
     if (it == ctx->last_spectrum.end() || count * sizeof(unsigned long long) > kStampTailFloats * sizeof(float)) return BLUR_ERR_INVALID;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, it->second + n, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));

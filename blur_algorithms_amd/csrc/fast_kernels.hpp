@@ -29,6 +29,9 @@
 #ifndef FK_HOIST_MAX_R
 #define FK_HOIST_MAX_R 10           // inner passes up to this radix read their twiddles up front
 #endif
+#ifndef FK_COL_PREFETCH
+#define FK_COL_PREFETCH 1           // column kernel, strip layout: load the next task's strip into registers during the passes
+#endif
 #ifndef FK_GATHER_UNROLL
 #define FK_GATHER_UNROLL 4          // independent strip-gather loads a thread keeps in flight (column kernel)
 #endif
@@ -81,11 +84,16 @@ struct FastEntry {
     int n;
     int npass;
     int radix[kMaxPassesDev];
-    // nframes frames back to back (u8: rows*cols*3 bytes each; planes: 3*rows*cols floats each)
-    hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* planes, int rows, int cols, int pad, int nframes,
+    // nframes frames back to back (u8: rows*cols*3 bytes each).
+    // Layout of the float intermediate, per frame and channel:
+    //   tile_w == 0: one row-major plane [rows][cols]
+    //   tile_w == 4 or 8: strips of tile_w columns, each strip contiguous: [strip][row][tile_w]
+    //     (what the column kernel consumes with fully coalesced 16-byte loads; the row kernel
+    //      then writes 2 rows x tile_w floats = whole 64-byte sectors per strip)
+    hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* planes, int rows, int cols, int pad, int nframes, int tile_w,
                          const float2* tw, const float* mperm);
-    // C = complex lines per workgroup (strip width / 2): 2 or 4
-    hipError_t (*col_u8)(hipStream_t, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes,
+    // C = complex lines per workgroup (strip width / 2): 2 or 4; tiled: planes are in the strip layout with tile_w = 2C
+    hipError_t (*col_u8)(hipStream_t, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,
                          const float2* tw, const float* mperm, int C);
     size_t (*col_lds_bytes)(int rows, int C);
 };
@@ -254,7 +262,7 @@ template <class PL, int T> struct Pass0Regs {
 // ======================================================================================
 // row pass
 // ======================================================================================
-template <class PL, int T, int CH>
+template <class PL, int T, int CH, int tile_shift>
 __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ planes,
                                                      int rows, int cols, int pad, int npairs, int nunits,
                                                      const float2* __restrict__ tw, const float* __restrict__ mperm)
@@ -267,6 +275,10 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
     float2* twl = z + PL::zs();
     const uint8_t* const src0 = src;
     float* const planes0 = planes;
+    // tile_shift > 0: strip layout [strip][row][tile_w], tile_w = 1 << tile_shift; 0: row-major
+    constexpr int tile_w = tile_shift ? 1 << tile_shift : 0;
+    const size_t plane_elems = tile_shift ? static_cast<size_t>((cols + tile_w - 1) >> tile_shift) * rows * tile_w
+                                          : static_cast<size_t>(rows) * cols;
     float* mpl = reinterpret_cast<float*>(twl + ((PL::lds_tw_count() + 1) & ~1));
 
 #ifdef FK_STAMPS
@@ -291,7 +303,7 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
     for (int u = u_begin; u < u_end; ++u) {
         const int f = u / npairs, pair = u - f * npairs;
         src = src0 + static_cast<size_t>(f) * rows * cols * CH;
-        planes = planes0 + static_cast<size_t>(f) * rows * cols * CH;
+        planes = planes0 + static_cast<size_t>(f) * plane_elems * CH;
         const int r0 = 2 * pair;
         const bool two = r0 + 1 < rows;
         const uint8_t* row_a = src + static_cast<size_t>(r0) * cols * CH;
@@ -344,8 +356,9 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
             FK_STAMP(6);       // inverse inner passes + barriers
 #endif
             // ---- inverse pass 0: LDS -> conj twiddle -> butterfly -> cropped float rows
-            float* out_a = planes + (static_cast<size_t>(c) * rows + r0) * cols;
-            float* out_b = out_a + cols;
+            float* out_a = planes + static_cast<size_t>(c) * plane_elems + (tile_shift ? static_cast<size_t>(r0) * tile_w : static_cast<size_t>(r0) * cols);
+            const int row_step = tile_shift ? tile_w : cols;                       // distance to the second row of the pair
+            const size_t strip_step = static_cast<size_t>(rows) * tile_w;         // tiled: distance between strips
 #pragma unroll
             for (int it = 0; it < Pass0Regs<PL, T>::IT; ++it) {
                 const int j = threadIdx.x + T * it;
@@ -362,8 +375,9 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
                         asm volatile("" ::"v"(v[k].x), "v"(v[k].y), "v"(x));
 #else
                         if (x >= 0 && x < cols) {
-                            out_a[x] = v[k].x;
-                            if (two) out_b[x] = v[k].y;
+                            float* o = tile_shift ? out_a + (x >> tile_shift) * strip_step + (x & (tile_w - 1)) : out_a + x;
+                            o[0] = v[k].x;
+                            if (two) o[row_step] = v[k].y;
                         }
 #endif
                     }
@@ -383,15 +397,17 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
 // ======================================================================================
 // column pass
 // ======================================================================================
-template <class PL, int T, int C, int CH>
+template <class PL, int T, int C, int CH, bool tiled>
 __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ planes, uint8_t* __restrict__ dst,
                                                      int rows, int cols, int pad, int nstrips, int nunits,
                                                      const float2* __restrict__ tw, const float* __restrict__ mperm)
 {
     static_assert(PL::valid(), "radices do not multiply to N");
+    static_assert(C % 2 == 0, "the tiled gather moves two complex lines (16 bytes) per load");
     constexpr int N = PL::N, P = PL::P, G = 2 * C;
     const float* const planes0 = planes;
     uint8_t* const dst0 = dst;
+    const size_t plane_elems = tiled ? static_cast<size_t>(nstrips) * rows * G : static_cast<size_t>(rows) * cols;
     constexpr int R0 = PL::R[0], m0 = PL::m(0);
     // pass 0: K thread groups of m0 butterflies, group gi takes lines gi, gi+K, ...
     constexpr int IT0 = Pass0Regs<PL, T>::IT;
@@ -406,6 +422,10 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
     const int gi = IT0 == 1 ? threadIdx.x / m0 : 0;
     const int j0 = IT0 == 1 ? threadIdx.x - gi * m0 : threadIdx.x;
     const bool p0_active = IT0 > 1 || gi < K;
+#ifdef FK_STAMPS
+    unsigned long long st_acc[kStampSlots] = {};
+    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
+#endif
     Pass0Regs<PL, T> p0;
     p0.load(tw, j0);
     for (int i = threadIdx.x; i < PL::lds_tw_count(); i += T) twl[i] = tw[PL::lds_tw_begin() + i];
@@ -420,17 +440,77 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
     const int wg_in_xcd = (static_cast<int>(gridDim.x) - xcd + 7) >> 3;
     const int u_begin = static_cast<int>(static_cast<long long>(xcd) * nunits / 8);
     const int u_end = static_cast<int>(static_cast<long long>(xcd + 1) * nunits / 8);
+    // Strip layout only: the gather of task t+1 = (unit, channel) is issued into REGISTERS when
+    // the passes of task t start and committed to LDS when they are done, so its ~2 us round
+    // trip hides behind the FFT instead of standing in front of it.
+    constexpr int KG = tiled ? (N * (C / 2) + T - 1) / T : 1;
+    float4 pf[KG];
+    bool pf_valid = false;
+    auto issue_gather = [&](int uu, int cc) {
+        const int ff = uu / nstrips, ss = uu - ff * nstrips;
+        const float* sb = planes0 + (static_cast<size_t>(ff) * CH + cc) * plane_elems + static_cast<size_t>(ss) * rows * G;
+#pragma unroll
+        for (int k = 0; k < KG; ++k) {
+            int idx = threadIdx.x + T * k;
+            idx = idx < N * (C / 2) ? idx : N * (C / 2) - 1;
+            const int p = idx / (C / 2), h = idx - p * (C / 2);
+            const int r = fk_reflect_src(p, pad, rows);
+            pf[k] = *reinterpret_cast<const float4*>(sb + static_cast<size_t>(r >= 0 ? r : 0) * G + 4 * h);
+        }
+    };
+    auto commit_gather = [&](int xx0) {
+#pragma unroll
+        for (int k = 0; k < KG; ++k) {
+            const int idx = threadIdx.x + T * k;
+            if (idx < N * (C / 2)) {
+                const int p = idx / (C / 2), h = idx - p * (C / 2);
+                const bool rv = fk_reflect_src(p, pad, rows) >= 0;
+                const int col = xx0 + 4 * h;
+                float4 t = pf[k];
+                if (!rv || col >= cols) t.x = 0.f;
+                if (!rv || col + 1 >= cols) t.y = 0.f;
+                if (!rv || col + 2 >= cols) t.z = 0.f;
+                if (!rv || col + 3 >= cols) t.w = 0.f;
+                z[(2 * h) * zs + PL::at(p)] = make_float2(t.x, t.y);
+                z[(2 * h + 1) * zs + PL::at(p)] = make_float2(t.z, t.w);
+            }
+        }
+    };
+
     for (int u = u_begin + lane_in_xcd; u < u_end; u += wg_in_xcd) {
         const int f = u / nstrips, strip = u - f * nstrips;
-        planes = planes0 + static_cast<size_t>(f) * rows * cols * CH;
+        planes = planes0 + static_cast<size_t>(f) * plane_elems * CH;
         dst = dst0 + static_cast<size_t>(f) * rows * cols * CH;
         const int x0 = strip * G;
         for (int ch = 0; ch < CH; ++ch) {
-            const float* plane = planes + static_cast<size_t>(ch) * rows * cols;
+            const float* plane = planes + static_cast<size_t>(ch) * plane_elems;
+            FK_STAMP(0);       // prologue / loop overhead / write-out of the previous strip
             __syncthreads();   // z free again (previous channel's inverse pass 0 has read it)
+            FK_STAMP(3);       // barrier
             // ---- gather: line l, position p  <-  plane[reflect(p)][x0 + 2l .. +1]
             const bool full = x0 + G <= cols && (cols & 1) == 0;
-            if (full) {
+            if constexpr (tiled && FK_COL_PREFETCH) {
+                if (!pf_valid) issue_gather(u, ch);        // first task of this workgroup
+                commit_gather(x0);
+            } else if constexpr (tiled) {
+                // strip layout: the whole strip is one contiguous block [row][G]; 16-byte loads, 1 KiB
+                // per wave instruction.  Columns beyond the image hold no data and are masked to zero.
+                const float* sb = plane + static_cast<size_t>(strip) * rows * G;
+                constexpr int H = C / 2;                       // float4 per position
+                FK_UNROLL(FK_GATHER_UNROLL)
+                for (int idx = threadIdx.x; idx < N * H; idx += T) {
+                    const int p = idx / H, h = idx - p * H;
+                    const int r = fk_reflect_src(p, pad, rows);
+                    float4 t = *reinterpret_cast<const float4*>(sb + static_cast<size_t>(r >= 0 ? r : 0) * G + 4 * h);
+                    const int col = x0 + 4 * h;
+                    if (r < 0 || col >= cols) t.x = 0.f;
+                    if (r < 0 || col + 1 >= cols) t.y = 0.f;
+                    if (r < 0 || col + 2 >= cols) t.z = 0.f;
+                    if (r < 0 || col + 3 >= cols) t.w = 0.f;
+                    z[(2 * h) * zs + PL::at(p)] = make_float2(t.x, t.y);
+                    z[(2 * h + 1) * zs + PL::at(p)] = make_float2(t.z, t.w);
+                }
+            } else if (full) {
                 // unconditional 8-byte loads (clamped row, masked value): the unrolled loop keeps
                 // several independent loads in flight per thread
                 FK_UNROLL(FK_GATHER_UNROLL)
@@ -451,7 +531,13 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
                     z[l * zs + PL::at(p)] = make_float2((r >= 0 && col < cols) ? a : 0.f, (r >= 0 && col + 1 < cols) ? b : 0.f);
                 }
             }
+            FK_STAMP(1);       // strip gather (global -> LDS)
             __syncthreads();
+            if constexpr (tiled && FK_COL_PREFETCH) {
+                const int nu = ch + 1 < CH ? u : u + wg_in_xcd, nch = ch + 1 < CH ? ch + 1 : 0;
+                pf_valid = nu < u_end;
+                if (pf_valid) issue_gather(nu, nch);
+            }
             // ---- pass 0 (register twiddles)
             if (p0_active) {
 #pragma unroll
@@ -473,10 +559,14 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
                 }
             }
             __syncthreads();
+            FK_STAMP(2);       // barrier + pass 0 + barrier
             fk_inner_passes<PL, 1, C, T, false>(z, zs, twl);
+            FK_STAMP(4);       // forward inner passes
             fk_mid_lds<PL, T, C>(z, zs, mpl);
             __syncthreads();
+            FK_STAMP(5);       // fused middle
             fk_inner_passes<PL, P - 2, C, T, true>(z, zs, twl);
+            FK_STAMP(6);       // inverse inner passes
             // ---- inverse pass 0 -> "+0.5f, truncate" -> pixel stage (Utils.hpp:189,204-206)
             if (p0_active) {
 #pragma unroll
@@ -505,6 +595,7 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
                 }
             }
         }
+        FK_STAMP(7);           // inverse pass 0 + pixel stage
         __syncthreads();
         // ---- write the strip as whole pixels: G*CH contiguous bytes per image row
         constexpr int RB = G * CH;
@@ -524,6 +615,13 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
             }
         }
     }
+#ifdef FK_STAMPS
+    FK_STAMP(0);
+    if (threadIdx.x == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(mperm) + N) + static_cast<size_t>(blockIdx.x) * kStampSlots;
+        for (int i = 0; i < kStampSlots; ++i) o[i] = st_acc[i];
+    }
+#endif
 }
 
 // ---- launchers ---------------------------------------------------------------------------
@@ -548,11 +646,12 @@ inline int fk_balanced_grid(int units, int slots)
 }
 constexpr int kNumCUs = 256;
 
-template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uint8_t* src, float* planes, int rows, int cols, int pad, int nframes,
+template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uint8_t* src, float* planes, int rows, int cols, int pad, int nframes, int tile_w,
                                                const float2* tw, const float* mperm)
 {
     const size_t lds = fk_row_lds<PL>();
-    auto kern = fast_rowpass_u8<PL, T, 3>;
+    if (tile_w != 0 && tile_w != 8) return hipErrorInvalidValue;
+    auto kern = tile_w ? fast_rowpass_u8<PL, T, 3, 3> : fast_rowpass_u8<PL, T, 3, 0>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
@@ -568,11 +667,12 @@ template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uin
     return hipGetLastError();
 }
 
-template <class PL, int T, int C> hipError_t fk_launch_col_u8_c(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes,
+template <class PL, int T, int C> hipError_t fk_launch_col_u8_c(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,
                                                          const float2* tw, const float* mperm)
 {
     const size_t lds = fk_col_lds<PL, C>(rows);
-    auto kern = fast_colpass_u8<PL, T, C, 3>;
+    if (tiled && C != 4) return hipErrorInvalidValue;          // the strip layout is 8 columns wide
+    auto kern = (tiled && C == 4) ? fast_colpass_u8<PL, T, C, 3, (C == 4)> : fast_colpass_u8<PL, T, C, 3, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
@@ -586,12 +686,12 @@ template <class PL, int T, int C> hipError_t fk_launch_col_u8_c(hipStream_t st, 
     return hipGetLastError();
 }
 
-template <class PL, int T> hipError_t fk_launch_col_u8(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes,
+template <class PL, int T> hipError_t fk_launch_col_u8(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,
                                                const float2* tw, const float* mperm, int C)
 {
     switch (C) {
-    case 4: return fk_launch_col_u8_c<PL, T, 4>(st, planes, dst, rows, cols, pad, nframes, tw, mperm);
-    case 2: return fk_launch_col_u8_c<PL, T, 2>(st, planes, dst, rows, cols, pad, nframes, tw, mperm);
+    case 4: return fk_launch_col_u8_c<PL, T, 4>(st, planes, dst, rows, cols, pad, nframes, tiled, tw, mperm);
+    case 2: return fk_launch_col_u8_c<PL, T, 2>(st, planes, dst, rows, cols, pad, nframes, tiled, tw, mperm);
     default: return hipErrorInvalidValue;
     }
 }
@@ -605,26 +705,47 @@ template <class PL> size_t fk_col_lds_bytes(int rows, int C)
     }
 }
 
-template <class PL, int TROW, int TCOL> FastEntry fk_make_entry()
+// A plan serves one role: the row pass and the column pass of the same FFT length want different
+// radix orders and thread counts (pass 0 should have about T butterflies; the column kernel also
+// carries the prefetch registers), so each role instantiates only its own kernel.
+template <class PL, int T> FastEntry fk_make_row_entry()
 {
     FastEntry e{};
     e.n = PL::N;
     e.npass = PL::P;
     for (int i = 0; i < PL::P; ++i) e.radix[i] = PL::R[i];
-    e.row_u8 = fk_launch_row_u8<PL, TROW>;
-    e.col_u8 = fk_launch_col_u8<PL, TCOL>;
+    e.row_u8 = fk_launch_row_u8<PL, T>;
+    return e;
+}
+
+template <class PL, int T> FastEntry fk_make_col_entry()
+{
+    FastEntry e{};
+    e.n = PL::N;
+    e.npass = PL::P;
+    for (int i = 0; i < PL::P; ++i) e.radix[i] = PL::R[i];
+    e.col_u8 = fk_launch_col_u8<PL, T>;
     e.col_lds_bytes = fk_col_lds_bytes<PL>;
     return e;
 }
 
 }  // namespace blur_amd
 
-// one translation unit per FFT length: BLUR_FAST_INSTANCE(4000, PAD, TROW, TCOL, 16, 10, 25)
-#define BLUR_FAST_INSTANCE(NN, PAD, TROW, TCOL, ...)                                                            \
+// one translation unit per (FFT length, role):
+//   BLUR_FAST_ROW(4000, PAD, T, 16, 10, 5, 5)      BLUR_FAST_COL(2304, PAD, T, 9, 16, 16)
+#define BLUR_FAST_ROW(NN, PAD, T, ...)                                                           \
     namespace blur_amd {                                                                         \
-    const FastEntry* fast_entry_##NN()                                                           \
+    const FastEntry* fast_row_entry_##NN()                                                       \
     {                                                                                            \
-        static const FastEntry e = fk_make_entry<StaticPlan<NN, PAD, __VA_ARGS__>, TROW, TCOL>();               \
+        static const FastEntry e = fk_make_row_entry<StaticPlan<NN, PAD, __VA_ARGS__>, T>();     \
+        return &e;                                                                               \
+    }                                                                                            \
+    }
+#define BLUR_FAST_COL(NN, PAD, T, ...)                                                           \
+    namespace blur_amd {                                                                         \
+    const FastEntry* fast_col_entry_##NN()                                                       \
+    {                                                                                            \
+        static const FastEntry e = fk_make_col_entry<StaticPlan<NN, PAD, __VA_ARGS__>, T>();     \
         return &e;                                                                               \
     }                                                                                            \
     }

@@ -83,6 +83,7 @@ FAST_CASES = [
     (170, 3840, 50.0),    # row 4320
     (2160, 170, 50.0),    # column 2560
     (1080, 1920, 20.0),   # BASELINE C2 whole: 2304 / 1280
+    (1081, 1923, 20.0),   # both passes specialised, odd x odd: ragged last strip in the strip layout
 ]
 
 
@@ -97,6 +98,10 @@ def test_specialised_lengths(ctx, rows, cols, sigma):
     assert_u8_parity(got.cpu().numpy(), want, planes)
     gen = ctx.pffft_(t, sigma, out=torch.empty_like(t), force_generic=True)
     assert_u8_parity(gen.cpu().numpy(), want, planes)
+    # the layout of the float intermediate (strips vs row-major planes) and the strip width are
+    # data-movement choices: the bytes must not change
+    assert torch.equal(got, ctx.pffft_(t, sigma, out=torch.empty_like(t), row_major_planes=True))
+    assert torch.equal(got, ctx.pffft_(t, sigma, out=torch.empty_like(t), col_group=4))
     # float planes of the specialised row pass against the oracle's `resf`
     rp = ctx.rowpass(t, sigma).cpu().numpy()
     _, inter = O.pffft_plane_f64(img[:, :, 1].astype(np.float32), sigma, True, want_inter=True)

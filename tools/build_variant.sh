@@ -1,7 +1,7 @@
 #!/bin/bash
-# tools/build_variant.sh NAME "N PAD TROW TCOL R,R,R" ...   [env: VFLAGS="-D..."]
+# tools/build_variant.sh NAME ["ROLE N PAD T R,R,R" ...]   [env: VFLAGS="-D..."]   ROLE = row | col
 # Builds blur_algorithms_amd/variants/libblur_amd_NAME.so with the given compile-time plans
-# (any length not listed keeps the plan of csrc/fast_N.hip).  For A/B runs on the GPU box:
+# (any (role, length) not listed keeps the plan of csrc/fast_ROLE_N.hip).  For A/B runs on the GPU box:
 #   BLUR_AMD_LIB=blur_algorithms_amd/variants/libblur_amd_NAME.so python tools/kbench.py
 set -e
 NAME=$1; shift
@@ -11,9 +11,10 @@ mkdir -p $BD /root/repo/blur_algorithms_amd/variants
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$CS $VFLAGS"
 for f in $CS/fast_*.hip; do cp $f $BD/; done
 for spec in "$@"; do set -- $spec
-cat > $BD/fast_$1.hip <<EOT
+U=$(echo $1 | tr a-z A-Z)
+cat > $BD/fast_$1_$2.hip <<EOT
 #include "fast_kernels.hpp"
-BLUR_FAST_INSTANCE($1, $2, $3, $4, $5)
+BLUR_FAST_$U($2, $3, $4, $5)
 EOT
 done
 pids=""

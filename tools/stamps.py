@@ -12,14 +12,16 @@ for _ in range(3):
     ctx.pffft_(frames, sigma, out=torch.empty_like(frames), frames_per_launch=int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 torch.cuda.synchronize()
 lib = _lib.load()
-lib.blur_debug_read_stamps.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+lib.blur_debug_read_stamps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
 nblk = 1080
 buf = np.zeros(nblk * 8, np.uint64)
-rc = lib.blur_debug_read_stamps(ctx._h, 4000, buf.ctypes.data, buf.size)
-st = buf.reshape(nblk, 8).astype(np.float64)
-st = st[st.sum(1) > 0]
-names = ["prologue/loop", "barrier A", "pass0+gload", "barrier B", "fwd inner", "mid", "inv inner", "inv pass0+store"]
-tot = st.sum(1)
-print("blocks with stamps: %d; cycles per block: mean %.0f  min %.0f  max %.0f" % (len(st), tot.mean(), tot.min(), tot.max()))
-for i, n in enumerate(names):
-    print("  %-18s mean %9.0f cyc  (%.1f%%)" % (n, st[:, i].mean(), 100 * st[:, i].mean() / tot.mean()))
+for n_fft, names in ((4000, ["prologue/loop", "barrier A", "pass0+gload", "barrier B", "fwd inner", "mid", "inv inner", "inv pass0+store"]),
+                     (2304, ["prologue/loop/writeout", "gather+barriers", "pass0", "last writeout", "fwd inner", "mid", "inv inner", "inv pass0+stage"])):
+    buf = np.zeros(nblk * 8, np.uint64)
+    rc = lib.blur_debug_read_stamps(ctx._h, n_fft, 1 if n_fft == 4000 else 2, buf.ctypes.data, buf.size)
+    st = buf.reshape(nblk, 8).astype(np.float64)
+    st = st[st.sum(1) > 0]
+    tot = st.sum(1)
+    print("N=%d: blocks with stamps: %d; cycles per block: mean %.0f  min %.0f  max %.0f" % (n_fft, len(st), tot.mean(), tot.min(), tot.max()))
+    for i, n in enumerate(names):
+        print("  %-24s mean %9.0f cyc  (%.1f%%)" % (n, st[:, i].mean(), 100 * st[:, i].mean() / tot.mean()))
