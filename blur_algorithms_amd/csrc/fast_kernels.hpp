@@ -32,6 +32,10 @@
 #ifndef FK_COL_PREFETCH
 #define FK_COL_PREFETCH 1           // column kernel, strip layout: load the next task's strip into registers during the passes
 #endif
+#ifndef FK_WAVE_LOCAL_ROW
+#define FK_WAVE_LOCAL_ROW 0         // row kernel: 1 = inner passes wave-local (no workgroup barriers between them)
+#endif
+// (the column kernel takes the same choice per plan: BLUR_FAST_COL's WL argument)
 #ifndef FK_GATHER_UNROLL
 #define FK_GATHER_UNROLL 4          // independent strip-gather loads a thread keeps in flight (column kernel)
 #endif
@@ -242,6 +246,127 @@ __device__ __forceinline__ void fk_mid_lds(float2* z, int zs, const float* __res
     }
 }
 
+// ---- wave-local inner section ------------------------------------------------------------------
+// After pass 0 a line falls apart into R0 independent sub-blocks of length m0 (element ranges
+// [q0*m0, (q0+1)*m0)): every later forward pass, the fused middle and every inverse pass except
+// the last stay inside one sub-block.  Each wave therefore OWNS whole sub-blocks (s = wave,
+// wave + W, ... over the R0*C sub-blocks of the workgroup's C lines) and runs all of those
+// passes on them without any workgroup barrier -- only the in-order LDS queue of the wave itself
+// orders its writes before its reads.  Barriers per line drop from 2P to 3.
+__device__ __forceinline__ void fk_wave_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <class PL, int I, int C, int T, bool INV>
+__device__ __forceinline__ void fk_inner_pass_wave(float2* z, int zs, const float2* twl)
+{
+    constexpr int R0 = PL::R[0], m0 = PL::m(0);
+    constexpr int R = PL::R[I], m = PL::m(I), nbs = m0 / R;       // butterflies per sub-block
+    constexpr int W = T / 64, S = R0 * C;
+    constexpr int off = PL::tw_off(I) - PL::lds_tw_begin();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int total = ((S - wave + W - 1) / W) * nbs;
+    FK_UNROLL(FK_INNER_UNROLL)
+    for (int g = lane; g < total; g += 64) {
+        const int i = g / nbs, bb = g - i * nbs;
+        const int sblk = wave + W * i;
+        const int c = sblk / R0, q0 = sblk - c * R0;
+        const int blk = bb / m, j = bb - blk * m;
+        const int base = q0 * m0 + blk * (R * m) + j;
+        float2* zc = z + c * zs;
+        float2 v[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = zc[PL::at(base + k * m)];
+        if constexpr (R <= FK_HOIST_MAX_R) {
+            float2 w[R];
+#pragma unroll
+            for (int q = 1; q < R; ++q) w[q] = twl[off + (q - 1) * m + j];
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!INV) {
+                Bfly<R, false>::run(v);
+                zc[PL::at(base)] = v[0];
+#pragma unroll
+                for (int q = 1; q < R; ++q) zc[PL::at(base + q * m)] = cmul(v[q], w[q]);
+            } else {
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], w[q]);
+                Bfly<R, true>::run(v);
+#pragma unroll
+                for (int k = 0; k < R; ++k) zc[PL::at(base + k * m)] = v[k];
+            }
+        } else {
+            if constexpr (!INV) {
+                Bfly<R, false>::run(v);
+                zc[PL::at(base)] = v[0];
+#pragma unroll
+                for (int q = 1; q < R; ++q) zc[PL::at(base + q * m)] = cmul(v[q], twl[off + (q - 1) * m + j]);
+            } else {
+#pragma unroll
+                for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], twl[off + (q - 1) * m + j]);
+                Bfly<R, true>::run(v);
+#pragma unroll
+                for (int k = 0; k < R; ++k) zc[PL::at(base + k * m)] = v[k];
+            }
+        }
+    }
+}
+
+template <class PL, int C, int T>
+__device__ __forceinline__ void fk_mid_wave(float2* z, int zs, const float* __restrict__ mpl)
+{
+    constexpr int R0 = PL::R[0], m0 = PL::m(0);
+    constexpr int R = PL::R[PL::P - 1], nbs = m0 / R;
+    constexpr int W = T / 64, S = R0 * C;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int total = ((S - wave + W - 1) / W) * nbs;
+    FK_UNROLL(FK_INNER_UNROLL)
+    for (int g = lane; g < total; g += 64) {
+        const int i = g / nbs, bb = g - i * nbs;
+        const int sblk = wave + W * i;
+        const int c = sblk / R0, q0 = sblk - c * R0;
+        const int base = q0 * m0 + bb * R;
+        float2* zc = z + c * zs;
+        float2 v[R];
+        float mm[R];
+#pragma unroll
+        for (int k = 0; k < R; ++k) v[k] = zc[PL::at(base + k)];
+#pragma unroll
+        for (int q = 0; q < R; ++q) mm[q] = mpl[base + q];
+        if constexpr (R <= FK_HOIST_MAX_R) __builtin_amdgcn_sched_barrier(0);
+        Bfly<R, false>::run(v);
+#pragma unroll
+        for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mm[q]);
+        Bfly<R, true>::run(v);
+#pragma unroll
+        for (int k = 0; k < R; ++k) zc[PL::at(base + k)] = v[k];
+    }
+}
+
+template <class PL, int I, int C, int T, bool INV>
+__device__ __forceinline__ void fk_inner_passes_wave(float2* z, int zs, const float2* twl)
+{
+    if constexpr (I >= 1 && I <= PL::P - 2) {
+        fk_inner_pass_wave<PL, I, C, T, INV>(z, zs, twl);
+        fk_wave_sync();
+        fk_inner_passes_wave<PL, (INV ? I - 1 : I + 1), C, T, INV>(z, zs, twl);
+    }
+}
+
+// forward inner passes, fused middle, inverse inner passes of the sub-blocks this wave owns;
+// the caller has a workgroup barrier before (pass 0 complete) and after (inverse pass 0 may start)
+template <class PL, int C, int T>
+__device__ __forceinline__ void fk_inner_section_wave(float2* z, int zs, const float2* twl, const float* __restrict__ mpl)
+{
+    static_assert(T % 64 == 0, "whole waves");
+    fk_inner_passes_wave<PL, 1, C, T, false>(z, zs, twl);
+    fk_mid_wave<PL, C, T>(z, zs, mpl);
+    fk_wave_sync();
+    fk_inner_passes_wave<PL, PL::P - 2, C, T, true>(z, zs, twl);
+}
+
 // pass-0 twiddles in registers: butterfly j = tid (+ T*it)
 template <class PL, int T> struct Pass0Regs {
     static constexpr int R = PL::R[0];
@@ -347,6 +472,11 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
             __syncthreads();
             FK_STAMP(3);       // barrier
 #ifndef FK_ABL_NOMIDDLE  // ablation build: only pass 0 and its inverse
+#if FK_WAVE_LOCAL_ROW
+            fk_inner_section_wave<PL, 1, T>(z, 0, twl, mid_tab);
+            __syncthreads();
+            FK_STAMP(4);       // wave-local inner section + barrier
+#else
             fk_inner_passes<PL, 1, 1, T, false>(z, 0, twl);
             FK_STAMP(4);       // forward inner passes + their barriers
             fk_mid_lds<PL, T, 1>(z, 0, mid_tab);
@@ -354,6 +484,7 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
             FK_STAMP(5);       // fused middle + barrier
             fk_inner_passes<PL, P - 2, 1, T, true>(z, 0, twl);
             FK_STAMP(6);       // inverse inner passes + barriers
+#endif
 #endif
             // ---- inverse pass 0: LDS -> conj twiddle -> butterfly -> cropped float rows
             float* out_a = planes + static_cast<size_t>(c) * plane_elems + (tile_shift ? static_cast<size_t>(r0) * tile_w : static_cast<size_t>(r0) * cols);
@@ -397,7 +528,7 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
 // ======================================================================================
 // column pass
 // ======================================================================================
-template <class PL, int T, int C, int CH, bool tiled>
+template <class PL, int T, int C, int CH, bool tiled, bool WL>
 __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ planes, uint8_t* __restrict__ dst,
                                                      int rows, int cols, int pad, int nstrips, int nunits,
                                                      const float2* __restrict__ tw, const float* __restrict__ mperm)
@@ -560,6 +691,11 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
             }
             __syncthreads();
             FK_STAMP(2);       // barrier + pass 0 + barrier
+            if constexpr (WL) {
+                fk_inner_section_wave<PL, C, T>(z, zs, twl, mpl);
+                __syncthreads();
+                FK_STAMP(4);   // wave-local inner section + barrier
+            } else {
             fk_inner_passes<PL, 1, C, T, false>(z, zs, twl);
             FK_STAMP(4);       // forward inner passes
             fk_mid_lds<PL, T, C>(z, zs, mpl);
@@ -567,6 +703,7 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
             FK_STAMP(5);       // fused middle
             fk_inner_passes<PL, P - 2, C, T, true>(z, zs, twl);
             FK_STAMP(6);       // inverse inner passes
+            }
             // ---- inverse pass 0 -> "+0.5f, truncate" -> pixel stage (Utils.hpp:189,204-206)
             if (p0_active) {
 #pragma unroll
@@ -667,12 +804,12 @@ template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uin
     return hipGetLastError();
 }
 
-template <class PL, int T, int C> hipError_t fk_launch_col_u8_c(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,
+template <class PL, int T, int C, bool WL> hipError_t fk_launch_col_u8_c(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,
                                                          const float2* tw, const float* mperm)
 {
     const size_t lds = fk_col_lds<PL, C>(rows);
     if (tiled && C != 4) return hipErrorInvalidValue;          // the strip layout is 8 columns wide
-    auto kern = (tiled && C == 4) ? fast_colpass_u8<PL, T, C, 3, (C == 4)> : fast_colpass_u8<PL, T, C, 3, false>;
+    auto kern = (tiled && C == 4) ? fast_colpass_u8<PL, T, C, 3, (C == 4), WL> : fast_colpass_u8<PL, T, C, 3, false, WL>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
@@ -686,12 +823,12 @@ template <class PL, int T, int C> hipError_t fk_launch_col_u8_c(hipStream_t st, 
     return hipGetLastError();
 }
 
-template <class PL, int T> hipError_t fk_launch_col_u8(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,
+template <class PL, int T, bool WL> hipError_t fk_launch_col_u8(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,
                                                const float2* tw, const float* mperm, int C)
 {
     switch (C) {
-    case 4: return fk_launch_col_u8_c<PL, T, 4>(st, planes, dst, rows, cols, pad, nframes, tiled, tw, mperm);
-    case 2: return fk_launch_col_u8_c<PL, T, 2>(st, planes, dst, rows, cols, pad, nframes, tiled, tw, mperm);
+    case 4: return fk_launch_col_u8_c<PL, T, 4, WL>(st, planes, dst, rows, cols, pad, nframes, tiled, tw, mperm);
+    case 2: return fk_launch_col_u8_c<PL, T, 2, WL>(st, planes, dst, rows, cols, pad, nframes, tiled, tw, mperm);
     default: return hipErrorInvalidValue;
     }
 }
@@ -718,13 +855,13 @@ template <class PL, int T> FastEntry fk_make_row_entry()
     return e;
 }
 
-template <class PL, int T> FastEntry fk_make_col_entry()
+template <class PL, int T, bool WL> FastEntry fk_make_col_entry()
 {
     FastEntry e{};
     e.n = PL::N;
     e.npass = PL::P;
     for (int i = 0; i < PL::P; ++i) e.radix[i] = PL::R[i];
-    e.col_u8 = fk_launch_col_u8<PL, T>;
+    e.col_u8 = fk_launch_col_u8<PL, T, WL>;
     e.col_lds_bytes = fk_col_lds_bytes<PL>;
     return e;
 }
@@ -732,7 +869,8 @@ template <class PL, int T> FastEntry fk_make_col_entry()
 }  // namespace blur_amd
 
 // one translation unit per (FFT length, role):
-//   BLUR_FAST_ROW(4000, PAD, T, 16, 10, 5, 5)      BLUR_FAST_COL(2304, PAD, T, 9, 16, 16)
+//   BLUR_FAST_ROW(4000, PAD, T, 16, 10, 5, 5)      BLUR_FAST_COL(2304, PAD, T, WL, 9, 16, 16)
+//   WL = 1: the inner passes run wave-local (no workgroup barrier between them), 0: with barriers
 #define BLUR_FAST_ROW(NN, PAD, T, ...)                                                           \
     namespace blur_amd {                                                                         \
     const FastEntry* fast_row_entry_##NN()                                                       \
@@ -741,11 +879,11 @@ template <class PL, int T> FastEntry fk_make_col_entry()
         return &e;                                                                               \
     }                                                                                            \
     }
-#define BLUR_FAST_COL(NN, PAD, T, ...)                                                           \
+#define BLUR_FAST_COL(NN, PAD, T, WL, ...)                                                           \
     namespace blur_amd {                                                                         \
     const FastEntry* fast_col_entry_##NN()                                                       \
     {                                                                                            \
-        static const FastEntry e = fk_make_col_entry<StaticPlan<NN, PAD, __VA_ARGS__>, T>();     \
+        static const FastEntry e = fk_make_col_entry<StaticPlan<NN, PAD, __VA_ARGS__>, T, (WL != 0)>();     \
         return &e;                                                                               \
     }                                                                                            \
     }

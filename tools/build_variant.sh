@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/build_variant.sh NAME ["ROLE N PAD T R,R,R" ...]   [env: VFLAGS="-D..."]   ROLE = row | col
+# tools/build_variant.sh NAME ["row N PAD T R,R,R" | "col N PAD T WL R,R,R" ...]   [env: VFLAGS="-D..."]   ROLE = row | col
 # Builds blur_algorithms_amd/variants/libblur_amd_NAME.so with the given compile-time plans
 # (any (role, length) not listed keeps the plan of csrc/fast_ROLE_N.hip).  For A/B runs on the GPU box:
 #   BLUR_AMD_LIB=blur_algorithms_amd/variants/libblur_amd_NAME.so python tools/kbench.py
@@ -14,7 +14,7 @@ for spec in "$@"; do set -- $spec
 U=$(echo $1 | tr a-z A-Z)
 cat > $BD/fast_$1_$2.hip <<EOT
 #include "fast_kernels.hpp"
-BLUR_FAST_$U($2, $3, $4, $5)
+BLUR_FAST_$U($2, $3, $4, $5${6:+, $6})
 EOT
 done
 pids=""
