@@ -242,6 +242,99 @@ __global__ __launch_bounds__(256) void boxsweep_kernel(const uint8_t* __restrict
     }
 }
 
+// Vertical sweep, four adjacent bytes (column-channels) per thread: dword loads/stores, lanes
+// cover 256 contiguous bytes of an image row, the walk along y is the accumulator recurrence.
+// Segments along y give the grid enough threads; each pays 2r+1 loads to start its window.
+__global__ __launch_bounds__(256) void boxcol4_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                      int h, int pitch4 /* dwords per row */, int r, int seg_len, int nseg)
+{
+    const long long gid = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    if (gid >= static_cast<long long>(pitch4) * nseg) return;
+    const int xq = static_cast<int>(gid % pitch4), seg = static_cast<int>(gid / pitch4);
+    const uint32_t* ip = reinterpret_cast<const uint32_t*>(in) + xq;
+    uint32_t* op = reinterpret_cast<uint32_t*>(out) + xq;
+    const float iarr = 1.f / static_cast<float>(r + r + 1);
+    const int ys = seg * seg_len, ye = min(h, ys + seg_len);
+    if (ys >= ye) return;
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    auto add = [&](int y, int sgn) {
+        const uint32_t v = ip[static_cast<size_t>(refl101(y, h)) * pitch4];
+        a0 += sgn * static_cast<int>(v & 0xffu);
+        a1 += sgn * static_cast<int>((v >> 8) & 0xffu);
+        a2 += sgn * static_cast<int>((v >> 16) & 0xffu);
+        a3 += sgn * static_cast<int>(v >> 24);
+    };
+    auto emit = [&](int y) {
+        const uint32_t b0 = static_cast<uint32_t>(static_cast<int>(static_cast<float>(a0) * iarr + 0.5f)) & 0xffu;
+        const uint32_t b1 = static_cast<uint32_t>(static_cast<int>(static_cast<float>(a1) * iarr + 0.5f)) & 0xffu;
+        const uint32_t b2 = static_cast<uint32_t>(static_cast<int>(static_cast<float>(a2) * iarr + 0.5f)) & 0xffu;
+        const uint32_t b3 = static_cast<uint32_t>(static_cast<int>(static_cast<float>(a3) * iarr + 0.5f)) & 0xffu;
+        op[static_cast<size_t>(y) * pitch4] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+    };
+    for (int d = -r; d <= r; ++d) add(ys + d, 1);
+    emit(ys);
+    for (int y = ys + 1; y < ye; ++y) {
+        add(y + r, 1);
+        add(y - r - 1, -1);
+        emit(y);
+    }
+}
+
+// All `passes` horizontal sweeps of one image row in one go: the row lives in LDS (two byte
+// buffers, ping-pong), each thread walks one (channel, segment) with the sliding accumulator,
+// u8 rounding after every sweep exactly as the per-sweep kernel does.  HBM sees the row once
+// in and once out instead of once per pass.
+__global__ __launch_bounds__(256) void boxrow_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                     int w, int C, int r, int passes, int seg_len, int nseg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rb = w * C;                               // bytes per row
+    const int rb4 = (rb + 3) & ~3;
+    uint8_t* a = reinterpret_cast<uint8_t*>(smem);
+    uint8_t* b = a + rb4;
+    const uint8_t* src = in + static_cast<size_t>(blockIdx.x) * rb;
+    uint8_t* dst = out + static_cast<size_t>(blockIdx.x) * rb;
+    if ((rb & 3) == 0) {
+        for (int i = threadIdx.x; i < rb / 4; i += 256) reinterpret_cast<uint32_t*>(a)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < rb; i += 256) a[i] = src[i];
+    }
+    __syncthreads();
+    const float iarr = 1.f / static_cast<float>(r + r + 1);
+    for (int p = 0; p < passes; ++p) {
+        for (int item = threadIdx.x; item < C * nseg; item += 256) {
+            const int c = item % C, seg = item / C;
+            const int xs = seg * seg_len, xe = min(w, xs + seg_len);
+            if (xs >= xe) continue;
+            const uint8_t* s = a + c;
+            uint8_t* d = b + c;
+            int acc = 0;
+            if (xs - r - 1 >= 0 && xe + r < w) {        // interior segment: no reflection anywhere
+                for (int x = xs - r; x <= xs + r; ++x) acc += s[x * C];
+                d[xs * C] = static_cast<uint8_t>(static_cast<int>(static_cast<float>(acc) * iarr + 0.5f));
+                for (int x = xs + 1; x < xe; ++x) {
+                    acc += s[(x + r) * C] - s[(x - r - 1) * C];
+                    d[x * C] = static_cast<uint8_t>(static_cast<int>(static_cast<float>(acc) * iarr + 0.5f));
+                }
+            } else {
+                for (int x = xs - r; x <= xs + r; ++x) acc += s[refl101(x, w) * C];
+                d[xs * C] = static_cast<uint8_t>(static_cast<int>(static_cast<float>(acc) * iarr + 0.5f));
+                for (int x = xs + 1; x < xe; ++x) {
+                    acc += s[refl101(x + r, w) * C] - s[refl101(x - r - 1, w) * C];
+                    d[x * C] = static_cast<uint8_t>(static_cast<int>(static_cast<float>(acc) * iarr + 0.5f));
+                }
+            }
+        }
+        __syncthreads();
+        uint8_t* t = a; a = b; b = t;
+    }
+    if ((rb & 3) == 0) {
+        for (int i = threadIdx.x; i < rb / 4; i += 256) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(a)[i];
+    } else {
+        for (int i = threadIdx.x; i < rb; i += 256) dst[i] = a[i];
+    }
+}
+
 }  // namespace
 
 // ======================================================================================
@@ -777,8 +870,35 @@ int blur_fastboxblur_u8_dev(blur_ctx* ctx, uint8_t* d_inout, int w, int h, int c
         hipLaunchKernelGGL(boxsweep_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, b, nlines, n, lstride, xstride, channels, r, seg_len);
         std::swap(a, b);
     };
-    for (int p = 0; p < passes; ++p) sweep(h, w, static_cast<size_t>(w) * channels, static_cast<size_t>(channels));
-    for (int p = 0; p < passes; ++p) sweep(w, h, static_cast<size_t>(channels), static_cast<size_t>(w) * channels);
+    // horizontal sweeps: all passes of a row inside LDS when two copies of the row fit
+    const size_t row_lds = 2 * ((static_cast<size_t>(w) * channels + 3) & ~static_cast<size_t>(3));
+    if (passes > 0 && row_lds <= kLdsLimit) {
+        if (int rc = set_lds(ctx, boxrow_kernel, row_lds)) return rc;
+        int r = (ksize - 1) / 2;
+        if (r > w - 1) r = w - 1;
+        const int nseg = std::max(1, 256 / channels);
+        const int seg_len = (w + nseg - 1) / nseg;
+        hipLaunchKernelGGL(boxrow_kernel, dim3(h), dim3(256), row_lds, ctx->stream, a, b, w, channels, r, passes, seg_len, nseg);
+        std::swap(a, b);
+    } else {
+        for (int p = 0; p < passes; ++p) sweep(h, w, static_cast<size_t>(w) * channels, static_cast<size_t>(channels));
+    }
+    if ((static_cast<size_t>(w) * channels) % 4 == 0) {
+        const int pitch4 = static_cast<int>(static_cast<size_t>(w) * channels / 4);
+        int r = (ksize - 1) / 2;
+        if (r > h - 1) r = h - 1;
+        // enough (dword column, segment) items to fill the chip a few times over
+        int nseg = std::max(1, std::min(h / std::max(2 * r + 1, 64), (256 * 2048) / std::max(1, pitch4) + 1));
+        const int seg_len = (h + nseg - 1) / nseg;
+        nseg = (h + seg_len - 1) / seg_len;
+        const long long items = static_cast<long long>(pitch4) * nseg;
+        for (int p = 0; p < passes; ++p) {
+            hipLaunchKernelGGL(boxcol4_kernel, dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0, ctx->stream, a, b, h, pitch4, r, seg_len, nseg);
+            std::swap(a, b);
+        }
+    } else {
+        for (int p = 0; p < passes; ++p) sweep(w, h, static_cast<size_t>(channels), static_cast<size_t>(w) * channels);
+    }
     HIP_TRY(ctx, hipGetLastError());
     if (a != d_inout) HIP_TRY(ctx, hipMemcpyAsync(d_inout, a, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return BLUR_OK;

@@ -211,6 +211,45 @@ def test_pieces_flip_block_and_interleave(ctx):
     assert np.array_equal(got, O.interleave_bgr(vals))
 
 
+def test_fastboxblur_config5_full_size(ctx):
+    """BASELINE config 5: 8K RGB, 3 passes, box width 41 (nearest odd to sqrt(12 sigma^2 / 3 + 1), sigma 20)"""
+    torch = _torch()
+    from oracle import oracle as O
+    img = np.random.default_rng(55).integers(0, 256, (4320, 7680, 3), dtype=np.uint8)
+    want = O.fastboxblur_u8(img, 41, 3)
+    got = ctx.fastboxblur(torch.from_numpy(img.copy()).cuda(), 41, 3).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_config3_frame_4k_sigma50(ctx):
+    """BASELINE config 3 whole: 4K, sigma 50 (kSize 331, FFT lengths 4320 / 2560)"""
+    torch = _torch()
+    from oracle import oracle as O
+    img = _rand_img(2160, 3840, 33)
+    want, planes = O.pffft_blur_u8c3_f64(img, 50.0, True, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    assert_u8_parity(ctx.pffft_(t, 50.0, out=torch.empty_like(t)).cpu().numpy(), want, planes)
+
+
+def test_batch_of_4k_frames_roundtrip_properties(ctx):
+    """BASELINE config 4 shape on one GPU (8 frames of 4K): size-independent properties --
+    every frame of the batch equals the same frame blurred alone, and blurring is idempotent
+    on a constant frame (no oracle needed at this size)"""
+    torch = _torch()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    frames = torch.randint(0, 256, (8, 2160, 3840, 3), dtype=torch.uint8, device="cuda", generator=g)
+    frames[3] = 117
+    out = ctx.pffft_(frames, 20.0, out=torch.empty_like(frames), nyquist_quirk=False)
+    assert int(out[3].min()) == 117 and int(out[3].max()) == 117
+    for i in (0, 5, 7):
+        one = ctx.pffft_(frames[i].contiguous(), 20.0, out=torch.empty_like(frames[i]), nyquist_quirk=False)
+        assert torch.equal(one, out[i])
+    # checksum of checksums is invariant to how the batch is chunked into launches
+    a = ctx.pffft_(frames, 20.0, out=torch.empty_like(frames), frames_per_launch=1)
+    b = ctx.pffft_(frames, 20.0, out=torch.empty_like(frames), frames_per_launch=3)
+    assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("w,h,ch,ksize,passes", [(97, 61, 3, 9, 2), (128, 64, 1, 5, 3), (50, 40, 3, 41, 3), (33, 20, 3, 81, 1)])
 def test_fastboxblur(ctx, w, h, ch, ksize, passes):
     torch = _torch()
