@@ -358,6 +358,8 @@ struct blur_ctx {
     std::map<int, float*> last_spectrum;   // n -> most recent table (diagnostic stamp read-back)
     float* work = nullptr;       // float planes of one frame
     size_t work_bytes = 0;
+    float* work2 = nullptr;      // second set of planes: very tall images only (column pass without the LDS pixel stage)
+    size_t work2_bytes = 0;
     uint8_t* box_tmp = nullptr;
     size_t box_bytes = 0;
     bool timing = false;
@@ -602,6 +604,24 @@ static int run_colpass_u8c3(blur_ctx* ctx, const float* planes, uint8_t* dst, in
         return BLUR_OK;
     }
     const size_t px = static_cast<size_t>(rows) * cols;
+    if (col_lds_bytes(p.col->dev.n, 1, rows, 3) > kLdsLimit && col_lds_bytes(p.col->dev.n, 1, rows, 0) <= kLdsLimit) {
+        // Very tall images: one complex line plus the u8 pixel stage no longer fit in LDS.  Run the
+        // column pass plane by plane into float planes (no stage) and interleave afterwards:
+        // 24 B/px more traffic, but the FFT length limit becomes that of a bare line (N <~ 19800).
+        if (ctx->work2_bytes < px * 3 * sizeof(float)) {
+            if (ctx->work2) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->work2)); ctx->work2 = nullptr; ctx->work2_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->work2), px * 3 * sizeof(float)));
+            ctx->work2_bytes = px * 3 * sizeof(float);
+        }
+        for (int f = 0; f < nframes; ++f) {
+            for (int c = 0; c < 3; ++c)
+                if (int rc = launch_colpass<float, 1>(ctx, planes + (f * 3 + c) * px, ctx->work2 + c * px, rows, cols, p.sz.pad, *p.col, p.m_col, p.col_group)) return rc;
+            const unsigned grid = static_cast<unsigned>(std::min<size_t>((px + 255) / 256, 2048u * 8));
+            hipLaunchKernelGGL(interleave_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->work2, dst + f * px * 3, static_cast<uint32_t>(px));
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        return BLUR_OK;
+    }
     for (int f = 0; f < nframes; ++f)
         if (int rc = launch_colpass<uint8_t, 3>(ctx, planes + f * px * 3, dst + f * px * 3, rows, cols, p.sz.pad, *p.col, p.m_col, p.col_group)) return rc;
     return BLUR_OK;
@@ -681,6 +701,7 @@ int blur_ctx_destroy(blur_ctx* ctx)
     for (auto& kv : ctx->plans) if (kv.second->d_tw) (void)hipFree(kv.second->d_tw);
     for (auto& kv : ctx->spectra) (void)hipFree(kv.second);
     if (ctx->work) (void)hipFree(ctx->work);
+    if (ctx->work2) (void)hipFree(ctx->work2);
     if (ctx->box_tmp) (void)hipFree(ctx->box_tmp);
     for (auto& t : ctx->ev_busy) { (void)hipEventDestroy(std::get<0>(t)); (void)hipEventDestroy(std::get<1>(t)); }
     for (auto& t : ctx->ev_free) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }

@@ -221,6 +221,19 @@ def test_fastboxblur_config5_full_size(ctx):
     assert np.array_equal(got, want)
 
 
+def test_very_tall_image_uses_planar_column_fallback(ctx):
+    """rows + 2 pad -> N0 = 12000: a complex line plus the u8 pixel stage exceed LDS, the engine
+    falls back to float planes + interleave (the reference's largest benchmark image is this tall)"""
+    torch = _torch()
+    from oracle import oracle as O
+    rows, cols, sigma = 10950, 352, 104.6
+    assert O.pffft_sizing(rows, cols, sigma)["N0"] == 12000
+    img = _rand_img(rows, cols, 77)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, True, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    assert_u8_parity(ctx.pffft_(t, sigma, out=torch.empty_like(t)).cpu().numpy(), want, planes)
+
+
 def test_config3_frame_4k_sigma50(ctx):
     """BASELINE config 3 whole: 4K, sigma 50 (kSize 331, FFT lengths 4320 / 2560)"""
     torch = _torch()
