@@ -6,4 +6,4 @@ is the thin host-side mirror of the reference's call surface over it.
 """
 from ._lib import BlurError, LIB_PATH  # noqa: F401
 from .api import (BlurContext, gaussian_window, getGaussian, isValidSize, nearestTransformSize,  # noqa: F401
-                  pffft_sizing, kernel_multipliers, fft_plan_radices)
+                  pffft_sizing, kernel_multipliers, fft_plan_radices, box_kernel, boxfft_sizing)

@@ -46,6 +46,10 @@ SYMBOLS = {
     "blur_gaussian_f32c1_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
     "blur_gaussian_u8c3_host": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
     "blur_gaussian_f32c1_host": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
+    "blur_separable_u8c3_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.POINTER(BlurOpts)]),
+    "blur_boxfft_u8c3_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
+    "blur_boxfft_sizing": (C.c_int, [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]),
+    "blur_box_kernel": (C.c_int, [_P, C.c_int, C.c_int]),
     "blur_rowpass_u8c3_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
     "blur_flip_block_f32_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "blur_deinterleave_bgr_u8_f32_dev": (C.c_int, [_P, _P, _P, C.c_uint32]),

@@ -59,6 +59,24 @@ def kernel_multipliers(sigma, ksize, n):
     return m
 
 
+def box_kernel(kLen, FFT_length):
+    """box_kernel(kernel, kLen, FFT_length), 1D form -- Source.cpp:129-140; returns the kernel"""
+    k = np.zeros(int(FFT_length), np.float32)
+    rc = _L().blur_box_kernel(k.ctypes.data, int(kLen), int(FFT_length))
+    if rc:
+        raise BlurError(rc, "box_kernel: bad arguments")
+    return k
+
+
+def boxfft_sizing(rows, cols, nsmooth):
+    """sizing of the `#define boxblur` mode of pffft_() -- Source.cpp:437-457"""
+    out = (C.c_int * 4)()
+    rc = _L().blur_boxfft_sizing(int(rows), int(cols), float(nsmooth), out)
+    if rc:
+        raise BlurError(rc, "boxfft_sizing: bad arguments")
+    return dict(kLen=out[0], pad=out[1], N0=out[2], N1=out[3])
+
+
 def fft_plan_radices(n):
     r = (C.c_int * 16)()
     k = _L().blur_fft_plan_radices(int(n), r)
@@ -151,6 +169,26 @@ class BlurContext:
         n = 1 if t.dim() == 3 else t.shape[0]
         rows, cols = t.shape[-3], t.shape[-2]
         self._check(self._lib.blur_gaussian_u8c3_batch_dev(self._h, t.data_ptr(), dst.data_ptr(), n, rows, cols, float(sigma), C.byref(o)))
+        return dst
+
+    def pffft_boxblur(self, image, nsmooth, out=None, nyquist_quirk=True):
+        """pffft_() compiled with `#define boxblur`: FFT-domain tent kernel (Source.cpp:437-442,468-472);
+        uint8 CUDA tensor [rows, cols, 3]"""
+        o = self._opts(nyquist_quirk)
+        dst = image if out is None else out
+        self.use_torch_stream()
+        self._check(self._lib.blur_boxfft_u8c3_dev(self._h, image.data_ptr(), dst.data_ptr(), image.shape[0], image.shape[1],
+                                                   float(nsmooth), C.byref(o)))
+        return dst
+
+    def separable(self, image, taps, pad=None, out=None, nyquist_quirk=True):
+        """any symmetric separable kernel (odd tap count) through the same engine; pad defaults to len(taps)//2"""
+        o = self._opts(nyquist_quirk)
+        t = np.ascontiguousarray(taps, np.float32)
+        dst = image if out is None else out
+        self.use_torch_stream()
+        self._check(self._lib.blur_separable_u8c3_dev(self._h, image.data_ptr(), dst.data_ptr(), image.shape[0], image.shape[1],
+                                                      t.ctypes.data, t.size, t.size // 2 if pad is None else int(pad), C.byref(o)))
         return dst
 
     def pffft_plane(self, plane, sigma, out=None, nyquist_quirk=True, col_group=0):

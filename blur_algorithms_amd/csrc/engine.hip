@@ -436,6 +436,29 @@ static int get_spectrum(blur_ctx* ctx, const DevicePlan& plan, double sigma, int
     return BLUR_OK;
 }
 
+// multiplier table of a caller-supplied n-periodic kernel (box/tent mode, user kernels); cached by content
+static int get_spectrum_custom(blur_ctx* ctx, const DevicePlan& plan, const std::vector<float>& karr, bool quirk, float** out)
+{
+    uint64_t h = 1469598103934665603ull;                         // FNV-1a over the kernel bytes
+    const unsigned char* bytes = reinterpret_cast<const unsigned char*>(karr.data());
+    for (size_t i = 0; i < karr.size() * sizeof(float); ++i) { h ^= bytes[i]; h *= 1099511628211ull; }
+    const auto key = std::make_tuple(plan.key, -1, quirk ? 1 : 0, h);
+    auto it = ctx->spectra.find(key);
+    if (it != ctx->spectra.end()) { *out = it->second; return BLUR_OK; }
+    const int n = plan.dev.n;
+    std::vector<float> m(n / 2 + 1), mp(n);
+    kernel_multipliers_from_array(karr.data(), n, m.data());
+    permuted_multipliers(plan.host, m.data(), quirk, mp.data());
+    float* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(float) * (n + kStampTailFloats)));
+    HIP_TRY(ctx, hipMemset(d, 0, sizeof(float) * (n + kStampTailFloats)));
+    HIP_TRY(ctx, hipMemcpy(d, mp.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    ctx->spectra[key] = d;
+    ctx->last_spectrum[plan.key] = d;
+    *out = d;
+    return BLUR_OK;
+}
+
 static int ensure_work(blur_ctx* ctx, size_t bytes)
 {
     if (ctx->work_bytes >= bytes) return BLUR_OK;
@@ -552,11 +575,29 @@ struct Prepared {
     size_t frame_elems = 0; // floats of intermediate per frame
 };
 
-static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p, bool u8c3 = true)
+// a caller-supplied separable kernel instead of the Gaussian: taps (odd count, centre in the middle)
+// or, for the tent mode, the reference's box_kernel arrays; pad as the caller's mode defines it
+struct CustomKernel {
+    const float* taps = nullptr;
+    int ksize = 0;
+    int pad = 0;
+    int box_klen = 0;      // > 0: build the arrays with box_kernel_1d(klen) instead of from taps
+};
+
+static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p, bool u8c3 = true,
+                   const CustomKernel* ck = nullptr)
 {
     if (!ctx) return BLUR_ERR_INVALID;
-    if (rows <= 0 || cols <= 0 || !(sigma > 0)) return fail(ctx, BLUR_ERR_INVALID, "rows, cols and sigma must be positive");
+    if (rows <= 0 || cols <= 0 || (!ck && !(sigma > 0))) return fail(ctx, BLUR_ERR_INVALID, "rows, cols and sigma must be positive");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ck) {
+        p.sz = Sizing{};
+        p.sz.kSize = ck->box_klen > 0 ? ck->box_klen : ck->ksize;
+        p.sz.pad = ck->pad;
+        auto fit = [](int want, int& tz) { const int n = is_valid_size(want) ? want : nearest_transform_size(want); tz = n - want; return n; };
+        p.sz.n_col = fit(rows + 2 * ck->pad, p.sz.tz_col);          // Source.cpp:445-457
+        p.sz.n_row = fit(cols + 2 * ck->pad, p.sz.tz_row);
+    } else
     p.sz = pffft_sizing(rows, cols, sigma);
     if (p.sz.pad > rows - 1 || p.sz.pad > cols - 1)
         return fail(ctx, BLUR_ERR_UNSUPPORTED, "pad > min(rows, cols) - 1: reflect-101 would read outside the image (README.md:33-38)");
@@ -572,8 +613,23 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         }
     if (int rc = get_plan(ctx, p.sz.n_row, allow_fast, false, &p.row)) return rc;
     if (int rc = get_plan(ctx, p.sz.n_col, allow_fast && p.col_fast_c > 0, true, &p.col)) return rc;
-    if (int rc = get_spectrum(ctx, *p.row, sigma, p.sz.kSize, quirk, &p.m_row)) return rc;
-    if (int rc = get_spectrum(ctx, *p.col, sigma, p.sz.kSize, quirk, &p.m_col)) return rc;
+    if (ck) {
+        for (int pass = 0; pass < 2; ++pass) {
+            DevicePlan* pl = pass ? p.col : p.row;
+            const int n = pl->dev.n;
+            std::vector<float> karr(n, 0.f);
+            if (ck->box_klen > 0) box_kernel_1d(karr.data(), ck->box_klen, n);
+            else {
+                if (ck->ksize > n) return fail(ctx, BLUR_ERR_INVALID, "kernel longer than the padded line");
+                const int c = ck->ksize / 2;
+                for (int t = 0; t < ck->ksize; ++t) karr[(t - c + n) % n] += ck->taps[t];   // centre at index 0 (README.md:93-101)
+            }
+            if (int rc = get_spectrum_custom(ctx, *pl, karr, quirk, pass ? &p.m_col : &p.m_row)) return rc;
+        }
+    } else {
+        if (int rc = get_spectrum(ctx, *p.row, sigma, p.sz.kSize, quirk, &p.m_row)) return rc;
+        if (int rc = get_spectrum(ctx, *p.col, sigma, p.sz.kSize, quirk, &p.m_col)) return rc;
+    }
     // strip layout of the intermediate only when both kernels understand it
     const bool no_tile = opts && opts->reserved[2] == 1;
     p.tile_w = (p.row->fast && p.col->fast && p.col_fast_c == 4 && !no_tile) ? 8 : 0;
@@ -745,13 +801,13 @@ int blur_ctx_timing(blur_ctx* ctx, double out_ms[2], int out_launches[2], int ou
     return BLUR_OK;
 }
 
-int blur_gaussian_u8c3_batch_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes,
-                                 int rows, int cols, double sigma, const blur_opts* opts)
+static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes,
+                                int rows, int cols, double sigma, const blur_opts* opts, const CustomKernel* ck)
 {
     if (!ctx) return BLUR_ERR_INVALID;
     if (!d_src || !d_dst || nframes < 0) return fail(ctx, BLUR_ERR_INVALID, "null frame pointer or negative frame count");
     Prepared p;
-    if (int rc = prepare(ctx, rows, cols, sigma, opts, p)) return rc;
+    if (int rc = prepare(ctx, rows, cols, sigma, opts, p, true, ck)) return rc;
     const size_t px = static_cast<size_t>(rows) * cols;
     // A few frames per launch pair: enough units to fill every CU evenly and to amortise the
     // per-workgroup table loads, few enough that the 12 B/px float intermediate of the chunk
@@ -769,6 +825,54 @@ int blur_gaussian_u8c3_batch_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d
         if (int rc = run_colpass_u8c3(ctx, ctx->work, d, rows, cols, nf, p)) return rc;
     }
     return BLUR_OK;
+}
+
+int blur_gaussian_u8c3_batch_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes,
+                                 int rows, int cols, double sigma, const blur_opts* opts)
+{
+    return blur_u8c3_batch_impl(ctx, d_src, d_dst, nframes, rows, cols, sigma, opts, nullptr);
+}
+
+int blur_separable_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int rows, int cols,
+                            const float* taps, int ksize, int pad, const blur_opts* opts)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!taps || ksize <= 0 || (ksize & 1) == 0 || pad < 0) return fail(ctx, BLUR_ERR_INVALID, "separable kernel: odd tap count and pad >= 0 required");
+    for (int t = 0; t < ksize / 2; ++t)
+        if (taps[t] != taps[ksize - 1 - t]) return fail(ctx, BLUR_ERR_UNSUPPORTED, "separable kernel must be symmetric (real spectrum, Source.cpp:419)");
+    CustomKernel ck;
+    ck.taps = taps; ck.ksize = ksize; ck.pad = pad;
+    return blur_u8c3_batch_impl(ctx, d_src, d_dst, 1, rows, cols, 0., opts, &ck);
+}
+
+int blur_boxfft_sizing(int rows, int cols, double nsmooth, int out[4])
+{
+    if (!out || rows <= 1 || cols <= 1 || !(nsmooth >= 1)) return BLUR_ERR_INVALID;
+    int klen, pad;
+    boxfft_sizing(rows, cols, nsmooth, klen, pad);
+    const int n0 = rows + 2 * pad, n1 = cols + 2 * pad;
+    out[0] = klen; out[1] = pad;
+    out[2] = is_valid_size(n0) ? n0 : nearest_transform_size(n0);
+    out[3] = is_valid_size(n1) ? n1 : nearest_transform_size(n1);
+    return BLUR_OK;
+}
+
+int blur_box_kernel(float* kernel, int klen, int fft_length)
+{
+    if (!kernel || klen <= 0 || fft_length < 2 * klen + 2) return BLUR_ERR_INVALID;
+    std::fill(kernel, kernel + fft_length, 0.f);
+    box_kernel_1d(kernel, klen, fft_length);
+    return BLUR_OK;
+}
+
+int blur_boxfft_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int rows, int cols, double nsmooth, const blur_opts* opts)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (rows <= 1 || cols <= 1 || !(nsmooth >= 1)) return fail(ctx, BLUR_ERR_INVALID, "boxfft: rows, cols > 1 and nsmooth >= 1 required");
+    CustomKernel ck;
+    boxfft_sizing(rows, cols, nsmooth, ck.box_klen, ck.pad);
+    if (ck.box_klen < 1) return fail(ctx, BLUR_ERR_INVALID, "boxfft: empty kernel");
+    return blur_u8c3_batch_impl(ctx, d_src, d_dst, 1, rows, cols, 0., opts, &ck);
 }
 
 int blur_gaussian_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int rows, int cols, double sigma, const blur_opts* opts)

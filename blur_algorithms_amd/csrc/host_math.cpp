@@ -98,6 +98,41 @@ void kernel_multipliers(double sigma, int ksize, int n, float* m)
     }
 }
 
+void box_kernel_1d(float* kernel, int klen, int n)
+{
+    // each tap t = -(klen-1) .. klen+1 receives, for every u = -(klen-1) .. klen-1, the double
+    // value clamp((klen-|u|)(klen-|t|)/klen^4, 0, 1) added into a FLOAT slot, u outermost:
+    // the order of the float additions is part of the result (Source.cpp:133-138)
+    const double scale = 1. / std::pow(klen, 4);
+    for (int u = 1 - klen; u <= klen - 1; ++u)
+        for (int t = 1 - klen; t <= klen + 1; ++t) {
+            const double w = std::clamp(static_cast<double>((klen - std::abs(u)) * (klen - std::abs(t))) * scale, 0., 1.);
+            float& slot = kernel[(t + n) % n];
+            slot = static_cast<float>(slot + w);
+        }
+}
+
+void boxfft_sizing(int rows, int cols, double nsmooth, int& klen, int& pad)
+{
+    const int whole = static_cast<int>(nsmooth);
+    const double side = std::sqrt(static_cast<double>(std::min(whole * whole, std::min(rows - 1, cols - 1))));
+    klen = static_cast<int>(side * side);
+    pad = (klen - 1) / 2 * 2;
+}
+
+void kernel_multipliers_from_array(const float* k, int n, float* m)
+{
+    const float scaler = 1.f / n;
+    const long double two_pi = 6.283185307179586476925286766559L;
+    std::vector<int> nz;
+    for (int i = 0; i < n; ++i) if (k[i] != 0.f) nz.push_back(i);
+    for (int b = 0; b <= n / 2; ++b) {
+        long double acc = 0;
+        for (int i : nz) acc += static_cast<long double>(k[i]) * cosl(two_pi * static_cast<long double>((static_cast<long long>(b) * i) % n) / n);
+        m[b] = static_cast<float>(acc) * scaler;
+    }
+}
+
 static void choose_radices(int n, std::vector<int>& out)
 {
     // Few LDS round trips matter more than flops: take the largest radix first.

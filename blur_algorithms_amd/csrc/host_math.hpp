@@ -27,6 +27,15 @@ Sizing pffft_sizing(int rows, int cols, double sigma);
 // m[b] = float(Re DFT(kernel)[b]) * (1.f / n), b = 0..n/2   (Source.cpp:423,506-507)
 void kernel_multipliers(double sigma, int ksize, int n, float* m);
 
+// box_kernel (1D), Source.cpp:129-140: the tent (box * box) kernel of the `#define boxblur` mode,
+// centred at index 0 of an n-periodic array (kernel: n floats, zero on entry)
+void box_kernel_1d(float* kernel, int klen, int n);
+// sizing of that mode, Source.cpp:437-442: kLen = kSize, pad = (kSize-1)/2 * 2
+void boxfft_sizing(int rows, int cols, double nsmooth, int& klen, int& pad);
+// m[b] = float(Re DFT(k)[b]) * (1.f / n) for an arbitrary n-periodic real kernel (only the real
+// part of the kernel spectrum is used, Source.cpp:423)
+void kernel_multipliers_from_array(const float* k, int n, float* m);
+
 // ---- FFT plan: in-place decimation-in-frequency forward, decimation-in-time inverse.
 // Forward pass i works on blocks of length len[i] = N / (radix[0]*...*radix[i-1]) with
 // m[i] = len[i] / radix[i]; after all passes frequency f sits at position pos with

@@ -132,6 +132,24 @@ int blur_gaussian_f32c1_host(blur_ctx* ctx, const float* src, float* dst,
 int blur_rowpass_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, float* d_planes,
                           int rows, int cols, double sigma, const blur_opts* opts);
 
+/* ---- other separable kernels on the same engine ------------------ */
+
+/* Any symmetric separable kernel instead of getGaussian(): taps[ksize] (HOST pointer, odd ksize,
+   centre tap in the middle, taps[i] == taps[ksize-1-i] so the spectrum is real, Source.cpp:419),
+   reflect-101 padding of `pad` pixels (>= ksize/2 for a linear convolution); the FFT lengths
+   follow Source.cpp:445-457 from pad.  Device frame pointers, asynchronous. */
+int blur_separable_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int rows, int cols,
+                            const float* taps, int ksize, int pad, const blur_opts* opts);
+
+/* The `#define boxblur` mode of pffft_() (Source.cpp:437-442,468-472): FFT-domain tent kernel
+   box_kernel(nsmooth^2) with passes = 2 padding. */
+int blur_boxfft_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int rows, int cols,
+                         double nsmooth, const blur_opts* opts);
+/* its sizing: out = { kLen, pad, sizes[0], sizes[1] }                     Source.cpp:437-457 */
+int blur_boxfft_sizing(int rows, int cols, double nsmooth, int out[4]);
+/* box_kernel(kernel, kLen, FFT_length), 1D form: fft_length floats (host)  Source.cpp:129-140 */
+int blur_box_kernel(float* kernel, int klen, int fft_length);
+
 /* ---- the pieces either side of it -------------------------------------------------- */
 
 /* flip_block<float,1>(in, out, w, h): out[x*h+y] = in[y*w+x]     call sites Source.cpp:540,562 */

@@ -312,6 +312,37 @@ void ora_kernel_multipliers(double sigma, int kSize, int N, float* m /* N/2+1 */
     free(k);
 }
 
+/* box_kernel (1D)                 Source.cpp:129-140  -- literal restatement, including the inner loop
+   bound `icol <= kLen + 1` (the two extra taps clamp to 0) and the float accumulation order.
+   kernel: FFT_length floats, zero on entry (the reference passes a zero-filled AlignedVector, :465). */
+void ora_box_kernel_1d(float* kernel, int kLen, int FFT_length)
+{
+    const double scale = 1. / pow(kLen, 4);
+    for (int irow = -kLen + 1; irow <= (kLen - 1); irow++)
+        for (int icol = -kLen + 1; icol <= (kLen + 1); icol++) {
+            const double kval = (double)((kLen - abs(irow)) * (kLen - abs(icol)));
+            double v = kval * scale;
+            v = v < 0. ? 0. : (v > 1. ? 1. : v);                     /* std::clamp(kval * scale, 0., 1.) */
+            kernel[(icol + FFT_length) % FFT_length] += v;           /* float += double */
+        }
+}
+
+/* multipliers of an arbitrary N-periodic real kernel: m[b] = float(Re DFT(k)[b]) * (1.f/N), b = 0..N/2
+   (the reference keeps only the real part of the kernel spectrum, Source.cpp:423) */
+void ora_kernel_multipliers_from_array(const float* k, int N, float* m)
+{
+    const float scaler = 1.f / N;
+    for (int b = 0; b <= N / 2; ++b) {
+        long double acc = 0;
+        for (int n = 0; n < N; ++n) {
+            if (k[n] == 0.f) continue;
+            const long long t = ((long long)b * n) % N;
+            acc += (long double)k[n] * cosl(2.0L * 3.14159265358979323846264338327950288L * (long double)t / N);
+        }
+        m[b] = (float)acc * scaler;
+    }
+}
+
 /* One 1D pass over `nlines` lines of length L (contiguous, stride L), float64
    arithmetic: reflect-pad (A6), forward DFT, pointwise rule (A7) with the
    Nyquist quirk if `quirk`, unnormalised inverse DFT, crop (A8).  Output is
@@ -648,6 +679,53 @@ int ora_pffft_blur_u8c3_f32(const uint8_t* src, uint8_t* dst, int rows, int cols
     }
     free(temp); free(kernel_row); free(kernel_col); free(kerf_row); free(kerf_col); free(tmpw); free(resf);
     return 0;
+}
+
+/* pffft_() with caller-supplied N-periodic kernels (row: N1 floats, col: N0 floats) and pad:
+   the FFT-domain box/tent mode (#define boxblur, Source.cpp:437-442,468-472) and any other
+   real-spectrum separable kernel.  N1/N0 follow Source.cpp:445-457 from `pad`. */
+int ora_pffft_blur_u8c3_f64_kernel(const uint8_t* src, uint8_t* dst, int rows, int cols, int pad,
+                                   const float* kern_row, const float* kern_col, int quirk, float* planes_out)
+{
+    int N0 = rows + 2 * pad, N1 = cols + 2 * pad;
+    if (!ora_is_valid_size(N0)) N0 = ora_nearest_transform_size(N0);
+    if (!ora_is_valid_size(N1)) N1 = ora_nearest_transform_size(N1);
+    if (pad > rows - 1 || pad > cols - 1) return -1;
+    const size_t px = (size_t)rows * cols;
+    float* m_row = (float*)malloc(sizeof(float) * (size_t)(N1 / 2 + 1));
+    float* m_col = (float*)malloc(sizeof(float) * (size_t)(N0 / 2 + 1));
+    ora_kernel_multipliers_from_array(kern_row, N1, m_row);
+    ora_kernel_multipliers_from_array(kern_col, N0, m_col);
+    float* pl = (float*)malloc(sizeof(float) * px * 3);
+    float* resf = (float*)malloc(sizeof(float) * px);
+    float* tr = (float*)malloc(sizeof(float) * px);
+    ora_deinterleave_bgr_u8_f32(src, pl, pl + px, pl + 2 * px, (uint32_t)px);
+    for (int c = 0; c < 3; ++c) {
+        float* plane = pl + c * px;
+        ora_pass_f64(plane, resf, rows, cols, pad, N1, m_row, quirk);
+        ora_flip_block_f32(resf, tr, cols, rows);
+        ora_pass_f64(tr, resf, cols, rows, pad, N0, m_col, quirk);
+        ora_flip_block_f32(resf, plane, rows, cols);
+    }
+    if (planes_out) memcpy(planes_out, pl, sizeof(float) * px * 3);
+    ora_interleave_bgr_f32_u8(pl, pl + px, pl + 2 * px, dst, (uint32_t)px);
+    free(m_row); free(m_col); free(pl); free(resf); free(tr);
+    return 0;
+}
+
+/* the `#define boxblur` branch of pffft_(): sizes per Source.cpp:437-442
+   out = { kLen (= kSize), pad, N0, N1 } */
+void ora_boxfft_sizing(int rows, int cols, double nsmooth, int out[4])
+{
+    int lim = rows - 1 < cols - 1 ? rows - 1 : cols - 1;
+    int sq = (int)nsmooth * (int)nsmooth;
+    nsmooth = sqrt((double)(sq < lim ? sq : lim));               /* :438 */
+    const int kSize = (int)(nsmooth * nsmooth);                  /* :440 (double product truncated to int) */
+    const int pad = (kSize - 1) / 2 * 2;                         /* :442, passes = 2 */
+    int N0 = rows + 2 * pad, N1 = cols + 2 * pad;
+    if (!ora_is_valid_size(N0)) N0 = ora_nearest_transform_size(N0);
+    if (!ora_is_valid_size(N1)) N1 = ora_nearest_transform_size(N1);
+    out[0] = kSize; out[1] = pad; out[2] = N0; out[3] = N1;
 }
 
 int ora_num_threads(void)

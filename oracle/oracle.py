@@ -63,6 +63,11 @@ def lib():
         L.ora_fastboxblur_u8.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.ora_fastboxblur_u8.restype = C.c_int
         L.ora_num_threads.restype = C.c_int
+        L.ora_box_kernel_1d.argtypes = [_f32p, C.c_int, C.c_int]
+        L.ora_kernel_multipliers_from_array.argtypes = [_f32p, C.c_int, _f32p]
+        L.ora_pffft_blur_u8c3_f64_kernel.argtypes = [_u8p, _u8p, C.c_int, C.c_int, C.c_int, _f32p, _f32p, C.c_int, C.c_void_p]
+        L.ora_pffft_blur_u8c3_f64_kernel.restype = C.c_int
+        L.ora_boxfft_sizing.argtypes = [C.c_int, C.c_int, C.c_double, _i32p]
         _lib = L
     return _lib
 
@@ -225,6 +230,40 @@ def fastboxblur_u8(img, ksize, passes):
     if rc:
         raise ValueError("bad fastboxblur arguments")
     return a
+
+
+def box_kernel_1d(klen, fft_length):
+    """box_kernel (1D), Source.cpp:129-140: tent kernel centred at index 0 of an N-periodic array"""
+    k = np.zeros(fft_length, np.float32)
+    lib().ora_box_kernel_1d(k, int(klen), int(fft_length))
+    return k
+
+
+def boxfft_sizing(rows, cols, nsmooth):
+    o = np.zeros(4, np.int32)
+    lib().ora_boxfft_sizing(rows, cols, float(nsmooth), o)
+    return dict(kLen=int(o[0]), pad=int(o[1]), N0=int(o[2]), N1=int(o[3]))
+
+
+def pffft_blur_u8c3_f64_kernel(img, pad, kern_row, kern_col, quirk=True, want_planes=False):
+    """pffft_() with caller-supplied N-periodic kernels (centre at index 0) and pad, float64 arithmetic"""
+    a = np.ascontiguousarray(img, np.uint8)
+    rows, cols, _ = a.shape
+    out = np.empty_like(a)
+    planes = np.empty((3, rows, cols), np.float32) if want_planes else None
+    rc = lib().ora_pffft_blur_u8c3_f64_kernel(a.reshape(-1), out.reshape(-1), rows, cols, int(pad),
+                                              np.ascontiguousarray(kern_row, np.float32), np.ascontiguousarray(kern_col, np.float32),
+                                              int(quirk), planes.ctypes.data if want_planes else None)
+    if rc:
+        raise ValueError("pad > min(rows, cols) - 1")
+    return (out, planes) if want_planes else out
+
+
+def pffft_boxblur_u8c3_f64(img, nsmooth, quirk=True, want_planes=False):
+    """the `#define boxblur` branch of pffft_() (Source.cpp:437-442,468-472): FFT-domain tent kernel"""
+    rows, cols, _ = img.shape
+    s = boxfft_sizing(rows, cols, nsmooth)
+    return pffft_blur_u8c3_f64_kernel(img, s["pad"], box_kernel_1d(s["kLen"], s["N1"]), box_kernel_1d(s["kLen"], s["N0"]), quirk, want_planes)
 
 
 def num_threads():

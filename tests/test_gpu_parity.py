@@ -221,6 +221,35 @@ def test_fastboxblur_config5_full_size(ctx):
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("rows,cols,nsmooth", [(120, 160, 3.0), (201, 333, 5.0), (64, 80, 2.0), (50, 60, 9.0)])
+def test_boxblur_mode_of_pffft(ctx, rows, cols, nsmooth):
+    """pffft_() compiled with `#define boxblur` (FFT-domain tent kernel, passes = 2)"""
+    torch = _torch()
+    from oracle import oracle as O
+    img = _rand_img(rows, cols, 17)
+    want, planes = O.pffft_boxblur_u8c3_f64(img, nsmooth, True, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    got = ctx.pffft_boxblur(t, nsmooth, out=torch.empty_like(t)).cpu().numpy()
+    assert_u8_parity(got, want, planes)
+
+
+def test_user_supplied_separable_kernel(ctx):
+    torch = _torch()
+    from oracle import oracle as O
+    taps = np.array([1, 4, 6, 4, 1], np.float32) / 16
+    img = _rand_img(90, 120, 19)
+    s = dict(N0=O.nearest_transform_size(90 + 4), N1=O.nearest_transform_size(120 + 4))
+    def periodic(n):
+        k = np.zeros(n, np.float32); k[0] = taps[2]; k[1] = taps[3]; k[2] = taps[4]; k[n - 1] = taps[1]; k[n - 2] = taps[0]; return k
+    want, planes = O.pffft_blur_u8c3_f64_kernel(img, 2, periodic(s["N1"]), periodic(s["N0"]), True, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    got = ctx.separable(t, taps, out=torch.empty_like(t)).cpu().numpy()
+    assert_u8_parity(got, want, planes)
+    import blur_algorithms_amd as B
+    with pytest.raises(B.BlurError):          # asymmetric kernels have a complex spectrum: refused
+        ctx.separable(t, np.array([1, 2, 3], np.float32) / 6, out=torch.empty_like(t))
+
+
 def test_very_tall_image_uses_planar_column_fallback(ctx):
     """rows + 2 pad -> N0 = 12000: a complex line plus the u8 pixel stage exceed LDS, the engine
     falls back to float planes + interleave (the reference's largest benchmark image is this tall)"""

@@ -55,6 +55,13 @@ def test_host_sizing_and_multipliers_equal_oracle():
         assert np.array_equal(B.kernel_multipliers(s, k, n), O.kernel_multipliers(s, k, n))
 
 
+def test_box_kernel_and_boxfft_sizing_equal_oracle():
+    for klen, n in [(9, 64), (25, 320), (4, 32), (49, 160)]:
+        assert np.array_equal(B.box_kernel(klen, n), O.box_kernel_1d(klen, n))
+    for rows, cols, ns in [(200, 300, 3.0), (50, 60, 9.0), (1080, 1920, 5.5), (33, 47, 2.0)]:
+        assert B.boxfft_sizing(rows, cols, ns) == O.boxfft_sizing(rows, cols, ns)
+
+
 def test_plans_cover_every_valid_length():
     supported = {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 25}
     for n in range(32, 13000, 32):
