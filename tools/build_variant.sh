@@ -8,7 +8,7 @@ NAME=$1; shift
 CS=/root/repo/blur_algorithms_amd/csrc
 BD=$CS/build_$NAME
 mkdir -p $BD /root/repo/blur_algorithms_amd/variants
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -I$CS $VFLAGS"
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -I$CS $VFLAGS"
 for f in $CS/fast_*.hip; do cp $f $BD/; done
 for spec in "$@"; do set -- $spec
 U=$(echo $1 | tr a-z A-Z)
