@@ -633,7 +633,8 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     // strip layout of the intermediate only when both kernels understand it
     const bool no_tile = opts && opts->reserved[2] == 1;
     p.tile_w = (p.row->fast && p.col->fast && p.col_fast_c == 4 && !no_tile) ? 8 : 0;
-    p.frame_elems = p.tile_w ? static_cast<size_t>((cols + p.tile_w - 1) / p.tile_w) * p.tile_w * rows * 3
+    // strip layout: [strip][row pair][8 columns][2 rows] per channel
+    p.frame_elems = p.tile_w ? static_cast<size_t>((cols + p.tile_w - 1) / p.tile_w) * ((rows + 1) / 2) * (2 * p.tile_w) * 3
                              : static_cast<size_t>(rows) * cols * 3;
     return BLUR_OK;
 }

@@ -27,7 +27,7 @@
 #define FK_INNER_UNROLL 1           // butterflies of an inner / middle pass a thread keeps in flight together
 #endif
 #ifndef FK_HOIST_MAX_R
-#define FK_HOIST_MAX_R 10           // inner passes up to this radix read their twiddles up front
+#define FK_HOIST_MAX_R 16           // inner passes up to this radix read their twiddles up front
 #endif
 #ifndef FK_COL_PREFETCH
 #define FK_COL_PREFETCH 1           // column kernel, strip layout: load the next task's strip into registers during the passes
@@ -91,9 +91,11 @@ struct FastEntry {
     // nframes frames back to back (u8: rows*cols*3 bytes each).
     // Layout of the float intermediate, per frame and channel:
     //   tile_w == 0: one row-major plane [rows][cols]
-    //   tile_w == 4 or 8: strips of tile_w columns, each strip contiguous: [strip][row][tile_w]
-    //     (what the column kernel consumes with fully coalesced 16-byte loads; the row kernel
-    //      then writes 2 rows x tile_w floats = whole 64-byte sectors per strip)
+    //   tile_w == 8: strips of 8 columns, each strip contiguous and row-PAIR interleaved:
+    //     [strip][row pair q][column 0..7][row 2q, row 2q+1]
+    //     (the row kernel's complex value (row a, row b) of one column is ONE 8-byte store, eight
+    //      neighbouring columns make a whole 64-byte sector; the column kernel streams the strip
+    //      with fully coalesced 16-byte loads: two columns x two rows each)
     hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* planes, int rows, int cols, int pad, int nframes, int tile_w,
                          const float2* tw, const float* mperm);
     // C = complex lines per workgroup (strip width / 2): 2 or 4; tiled: planes are in the strip layout with tile_w = 2C
@@ -400,9 +402,9 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
     float2* twl = z + PL::zs();
     const uint8_t* const src0 = src;
     float* const planes0 = planes;
-    // tile_shift > 0: strip layout [strip][row][tile_w], tile_w = 1 << tile_shift; 0: row-major
+    // tile_shift > 0: strip layout [strip][row pair][tile_w columns][2 rows], tile_w = 1 << tile_shift; 0: row-major
     constexpr int tile_w = tile_shift ? 1 << tile_shift : 0;
-    const size_t plane_elems = tile_shift ? static_cast<size_t>((cols + tile_w - 1) >> tile_shift) * rows * tile_w
+    const size_t plane_elems = tile_shift ? static_cast<size_t>((cols + tile_w - 1) >> tile_shift) * npairs * (2 * tile_w)
                                           : static_cast<size_t>(rows) * cols;
     float* mpl = reinterpret_cast<float*>(twl + ((PL::lds_tw_count() + 1) & ~1));
 
@@ -487,9 +489,8 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
 #endif
 #endif
             // ---- inverse pass 0: LDS -> conj twiddle -> butterfly -> cropped float rows
-            float* out_a = planes + static_cast<size_t>(c) * plane_elems + (tile_shift ? static_cast<size_t>(r0) * tile_w : static_cast<size_t>(r0) * cols);
-            const int row_step = tile_shift ? tile_w : cols;                       // distance to the second row of the pair
-            const size_t strip_step = static_cast<size_t>(rows) * tile_w;         // tiled: distance between strips
+            float* out_a = planes + static_cast<size_t>(c) * plane_elems + (tile_shift ? static_cast<size_t>(pair) * (2 * tile_w) : static_cast<size_t>(r0) * cols);
+            const size_t strip_step = static_cast<size_t>(npairs) * (2 * tile_w);   // tiled: distance between strips
 #pragma unroll
             for (int it = 0; it < Pass0Regs<PL, T>::IT; ++it) {
                 const int j = threadIdx.x + T * it;
@@ -506,9 +507,13 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
                         asm volatile("" ::"v"(v[k].x), "v"(v[k].y), "v"(x));
 #else
                         if (x >= 0 && x < cols) {
-                            float* o = tile_shift ? out_a + (x >> tile_shift) * strip_step + (x & (tile_w - 1)) : out_a + x;
-                            o[0] = v[k].x;
-                            if (two) o[row_step] = v[k].y;
+                            if constexpr (tile_shift != 0) {
+                                // (row a, row b) of this column: one 8-byte store (row b is 0 when the image has no such row)
+                                *reinterpret_cast<float2*>(out_a + (x >> tile_shift) * strip_step + 2 * (x & (tile_w - 1))) = v[k];
+                            } else {
+                                out_a[x] = v[k].x;
+                                if (two) out_a[cols + x] = v[k].y;
+                            }
                         }
 #endif
                     }
@@ -538,7 +543,8 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
     constexpr int N = PL::N, P = PL::P, G = 2 * C;
     const float* const planes0 = planes;
     uint8_t* const dst0 = dst;
-    const size_t plane_elems = tiled ? static_cast<size_t>(nstrips) * rows * G : static_cast<size_t>(rows) * cols;
+    const int npairs = (rows + 1) / 2;
+    const size_t plane_elems = tiled ? static_cast<size_t>(nstrips) * npairs * (2 * G) : static_cast<size_t>(rows) * cols;
     constexpr int R0 = PL::R[0], m0 = PL::m(0);
     // pass 0: K thread groups of m0 butterflies, group gi takes lines gi, gi+K, ...
     constexpr int IT0 = Pass0Regs<PL, T>::IT;
@@ -574,37 +580,48 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
     // Strip layout only: the gather of task t+1 = (unit, channel) is issued into REGISTERS when
     // the passes of task t start and committed to LDS when they are done, so its ~2 us round
     // trip hides behind the FFT instead of standing in front of it.
-    constexpr int KG = tiled ? (N * (C / 2) + T - 1) / T : 1;
+    // Gather of one (strip, channel): for every line l (two columns) ONE 16-byte load per storage
+    // row pair (two columns x two rows -> two positions of line l).  The reflected border
+    // positions are then copied inside LDS from the body rows they mirror (Source.cpp:525-529),
+    // the trailing zeros written; neither needs global memory.
+    const int n_items = npairs * C;
+    constexpr int KG = tiled ? ((N / 2) * C + T - 1) / T : 1;      // rows <= N - 2 pad  =>  npairs <= N/2
     float4 pf[KG];
     bool pf_valid = false;
     auto issue_gather = [&](int uu, int cc) {
         const int ff = uu / nstrips, ss = uu - ff * nstrips;
-        const float* sb = planes0 + (static_cast<size_t>(ff) * CH + cc) * plane_elems + static_cast<size_t>(ss) * rows * G;
+        const float* sb = planes0 + (static_cast<size_t>(ff) * CH + cc) * plane_elems + static_cast<size_t>(ss) * npairs * (2 * G);
 #pragma unroll
         for (int k = 0; k < KG; ++k) {
             int idx = threadIdx.x + T * k;
-            idx = idx < N * (C / 2) ? idx : N * (C / 2) - 1;
-            const int p = idx / (C / 2), h = idx - p * (C / 2);
-            const int r = fk_reflect_src(p, pad, rows);
-            pf[k] = *reinterpret_cast<const float4*>(sb + static_cast<size_t>(r >= 0 ? r : 0) * G + 4 * h);
+            idx = idx < n_items ? idx : n_items - 1;
+            const int q = idx / C, l = idx - q * C;
+            pf[k] = *reinterpret_cast<const float4*>(sb + static_cast<size_t>(q) * (2 * G) + 4 * l);
         }
     };
     auto commit_gather = [&](int xx0) {
 #pragma unroll
         for (int k = 0; k < KG; ++k) {
             const int idx = threadIdx.x + T * k;
-            if (idx < N * (C / 2)) {
-                const int p = idx / (C / 2), h = idx - p * (C / 2);
-                const bool rv = fk_reflect_src(p, pad, rows) >= 0;
-                const int col = xx0 + 4 * h;
-                float4 t = pf[k];
-                if (!rv || col >= cols) t.x = 0.f;
-                if (!rv || col + 1 >= cols) t.y = 0.f;
-                if (!rv || col + 2 >= cols) t.z = 0.f;
-                if (!rv || col + 3 >= cols) t.w = 0.f;
-                z[(2 * h) * zs + PL::at(p)] = make_float2(t.x, t.y);
-                z[(2 * h + 1) * zs + PL::at(p)] = make_float2(t.z, t.w);
+            if (idx < n_items) {
+                const int q = idx / C, l = idx - q * C;
+                const int col = xx0 + 2 * l;
+                float4 t = pf[k];                                 // (a_col, b_col, a_col+1, b_col+1): rows a = 2q, b = 2q+1
+                if (col >= cols) { t.x = 0.f; t.y = 0.f; }        // columns beyond the image hold no data
+                if (col + 1 >= cols) { t.z = 0.f; t.w = 0.f; }
+                float2* zl = z + l * zs;
+                zl[PL::at(pad + 2 * q)] = make_float2(t.x, t.z);
+                if (2 * q + 1 < rows) zl[PL::at(pad + 2 * q + 1)] = make_float2(t.y, t.w);
             }
+        }
+        __syncthreads();
+        // reflect-101 borders from the rows already in LDS, and the trailing zeros
+        for (int idx = threadIdx.x; idx < (N - rows) * C; idx += T) {
+            const int e = idx / C, l = idx - e * C;
+            const int p = e < pad ? e : rows + e;                 // 0..pad-1, then pad+rows .. N-1
+            const int r = fk_reflect_src(p, pad, rows);
+            float2* zl = z + l * zs;
+            zl[PL::at(p)] = r >= 0 ? zl[PL::at(pad + r)] : make_float2(0.f, 0.f);
         }
     };
 
@@ -620,27 +637,9 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
             FK_STAMP(3);       // barrier
             // ---- gather: line l, position p  <-  plane[reflect(p)][x0 + 2l .. +1]
             const bool full = x0 + G <= cols && (cols & 1) == 0;
-            if constexpr (tiled && FK_COL_PREFETCH) {
-                if (!pf_valid) issue_gather(u, ch);        // first task of this workgroup
+            if constexpr (tiled) {
+                if (!pf_valid) issue_gather(u, ch);        // first task of this workgroup, or prefetch disabled
                 commit_gather(x0);
-            } else if constexpr (tiled) {
-                // strip layout: the whole strip is one contiguous block [row][G]; 16-byte loads, 1 KiB
-                // per wave instruction.  Columns beyond the image hold no data and are masked to zero.
-                const float* sb = plane + static_cast<size_t>(strip) * rows * G;
-                constexpr int H = C / 2;                       // float4 per position
-                FK_UNROLL(FK_GATHER_UNROLL)
-                for (int idx = threadIdx.x; idx < N * H; idx += T) {
-                    const int p = idx / H, h = idx - p * H;
-                    const int r = fk_reflect_src(p, pad, rows);
-                    float4 t = *reinterpret_cast<const float4*>(sb + static_cast<size_t>(r >= 0 ? r : 0) * G + 4 * h);
-                    const int col = x0 + 4 * h;
-                    if (r < 0 || col >= cols) t.x = 0.f;
-                    if (r < 0 || col + 1 >= cols) t.y = 0.f;
-                    if (r < 0 || col + 2 >= cols) t.z = 0.f;
-                    if (r < 0 || col + 3 >= cols) t.w = 0.f;
-                    z[(2 * h) * zs + PL::at(p)] = make_float2(t.x, t.y);
-                    z[(2 * h + 1) * zs + PL::at(p)] = make_float2(t.z, t.w);
-                }
             } else if (full) {
                 // unconditional 8-byte loads (clamped row, masked value): the unrolled loop keeps
                 // several independent loads in flight per thread
