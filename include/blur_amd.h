@@ -49,7 +49,7 @@ typedef struct blur_opts {
     int col_group;
     /* reserved[0] = 1: use the run-time-planned kernels even where a compile-time specialised
        one exists (tests); reserved[1] > 0: frames per launch pair of the batch entry point
-       (0 = auto: as many as keep the float intermediate within the Infinity Cache);
+       (0 = auto: as many as fit a 1 GiB float workspace);
        reserved[2] = 1: keep the float intermediate in row-major planes even when both passes are
        specialised (default: strips of 8 columns stored contiguously) */
     int reserved[6];
