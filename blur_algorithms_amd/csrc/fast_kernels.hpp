@@ -735,7 +735,17 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
         __syncthreads();
         // ---- write the strip as whole pixels: G*CH contiguous bytes per image row
         constexpr int RB = G * CH;
-        if (x0 + G <= cols && ((cols * CH) & 3) == 0 && (RB & 3) == 0) {
+        if (x0 + G <= cols && ((cols * CH) & 7) == 0 && (RB & 7) == 0) {
+            // 8-byte stores: three per image row of the strip
+            constexpr int RQ = RB / 8;
+            const uint2* s64 = reinterpret_cast<const uint2*>(stage);
+            FK_UNROLL(4)
+            for (int idx = threadIdx.x; idx < rows * RQ; idx += T) {
+                const int r = idx / RQ, d = idx - r * RQ;
+                uint2* o = reinterpret_cast<uint2*>(dst + (static_cast<size_t>(r) * cols + x0) * CH);
+                o[d] = s64[idx];
+            }
+        } else if (x0 + G <= cols && ((cols * CH) & 3) == 0 && (RB & 3) == 0) {
             constexpr int RD = RB / 4;
             const uint32_t* s32 = reinterpret_cast<const uint32_t*>(stage);
             for (int idx = threadIdx.x; idx < rows * RD; idx += T) {
