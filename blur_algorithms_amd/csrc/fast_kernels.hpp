@@ -23,6 +23,9 @@
 #ifndef FK_ROW_MID_GLOBAL
 #define FK_ROW_MID_GLOBAL 0         // 1: middle-pass multipliers straight from global/L1 instead of LDS
 #endif
+#ifndef FK_ROW_MID_REGS
+#define FK_ROW_MID_REGS 0           // 1: row kernel keeps the middle-pass multipliers of its butterflies in registers
+#endif
 #ifndef FK_INNER_UNROLL
 #define FK_INNER_UNROLL 1           // butterflies of an inner / middle pass a thread keeps in flight together
 #endif
@@ -415,7 +418,12 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
     Pass0Regs<PL, T> p0;
     p0.load(tw, threadIdx.x);
     for (int i = threadIdx.x; i < PL::lds_tw_count(); i += T) twl[i] = tw[PL::lds_tw_begin() + i];
-#if FK_ROW_MID_GLOBAL
+#if FK_ROW_MID_REGS
+    (void)mpl;
+    const float* mid_tab = mperm;
+    MidRegs<PL, T, 1> mid_regs;
+    mid_regs.load(mperm);
+#elif FK_ROW_MID_GLOBAL
     (void)mpl;
     const float* mid_tab = mperm;
 #else
@@ -481,7 +489,11 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
 #else
             fk_inner_passes<PL, 1, 1, T, false>(z, 0, twl);
             FK_STAMP(4);       // forward inner passes + their barriers
+#if FK_ROW_MID_REGS
+            mid_regs.run(z, 0);
+#else
             fk_mid_lds<PL, T, 1>(z, 0, mid_tab);
+#endif
             __syncthreads();
             FK_STAMP(5);       // fused middle + barrier
             fk_inner_passes<PL, P - 2, 1, T, true>(z, 0, twl);
@@ -774,7 +786,7 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
 template <class PL> size_t fk_row_lds()
 {
     return (static_cast<size_t>(PL::zs()) + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) +
-           (FK_ROW_MID_GLOBAL ? 0 : static_cast<size_t>(PL::N) * sizeof(float));
+           ((FK_ROW_MID_GLOBAL || FK_ROW_MID_REGS) ? 0 : static_cast<size_t>(PL::N) * sizeof(float));
 }
 
 template <class PL, int C> size_t fk_col_lds(int rows)
