@@ -11,6 +11,7 @@
 //   deinterleave_BGR(in, planes, total) / interleave_BGR    Utils.hpp:159-210
 //   Reflect_101<T,C>(in, out, top, bottom, left, right, sz) Utils.hpp:212-243
 //   hybrid_loop(end, op)                                    Utils.hpp:16-55
+//   PFAlloc<T>, AlignedVector<T>                            Utils.hpp:57-138, Source.cpp:58
 //   flip_block<T,C>(in, out, w, h)                          call sites Source.cpp:540,562
 //   fastboxblur(in, w, h, channels, ksize, passes)          call site  Source.cpp:587
 //   pffft_(image, sigma)                                    Source.cpp:429-570
@@ -25,6 +26,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -56,6 +58,24 @@ inline blur_ctx* default_ctx()
     static Holder h;
     return h.c;
 }
+
+// ---- PFAlloc / AlignedVector (Utils.hpp:57-138, Source.cpp:58): 64-byte aligned float storage.
+// The GPU path does not need it; it is here so that code written against the reference's types compiles.
+template <class T> struct PFAlloc {
+    using value_type = T;
+    PFAlloc() noexcept = default;
+    template <class U> PFAlloc(const PFAlloc<U>&) noexcept {}
+    T* allocate(std::size_t n)
+    {
+        void* p = nullptr;
+        if (posix_memalign(&p, 64, (n ? n : 1) * sizeof(T)) != 0) throw std::bad_alloc();
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, std::size_t) noexcept { std::free(p); }
+    template <class U> bool operator==(const PFAlloc<U>&) const noexcept { return true; }
+    template <class U> bool operator!=(const PFAlloc<U>&) const noexcept { return false; }
+};
+template <typename T> using AlignedVector = std::vector<T, PFAlloc<T>>;
 
 // ---- sizing ---------------------------------------------------------------------------
 inline int gaussian_window(const double sigma, const int max_width = 0) { return blur_gaussian_window(sigma, max_width); }
@@ -164,6 +184,7 @@ template <class Mat, class = decltype(std::declval<Mat&>().size[0])> void pffft_
 }  // namespace blur_amd
 
 #ifdef BLUR_AMD_GLOBAL_NAMES
+using blur_amd::compat::AlignedVector;
 using blur_amd::compat::deinterleave_BGR;
 using blur_amd::compat::fastboxblur;
 using blur_amd::compat::flip_block;

@@ -34,6 +34,11 @@ static int host_checks()
     REQUIRE(k.size() == 8 && k[2] == 0 && k[6] == 0 && k[1] == k[7] && k[0] > k[1]);
     getGaussian(k, 2.0);
     REQUIRE((int)k.size() == gaussian_window(2.0));
+    AlignedVector<float> ak(16), ak2;                  // the reference's aligned container (Source.cpp:465)
+    getGaussian(ak, 1.0, 3, 8);
+    REQUIRE(ak.size() == 8 && ak[0] == k.size() * 0 + ak[0] && (reinterpret_cast<uintptr_t>(ak.data()) & 63) == 0);
+    ak2 = ak;                                          // Source.cpp:503 needs allocator equality
+    REQUIRE(ak2 == ak);
     // README.md:49-52: length 7, pad 6 -> g f e d c b | A..G | f e d c b a
     const uint8_t row[7] = { 1, 2, 3, 4, 5, 6, 7 };
     uint8_t padded[19];

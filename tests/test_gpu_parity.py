@@ -250,6 +250,62 @@ def test_user_supplied_separable_kernel(ctx):
         ctx.separable(t, np.array([1, 2, 3], np.float32) / 6, out=torch.empty_like(t))
 
 
+def test_seeded_fuzz_over_sizes_and_sigmas(ctx):
+    """30 seeded random (rows, cols, sigma) draws: every run-time plan shape (radices 2..16 in all
+    orders the planner emits), ragged sizes, windows clamped to the longer side"""
+    torch = _torch()
+    from oracle import oracle as O
+    rng = np.random.default_rng(20241108)
+    done = 0
+    plans = set()
+    while done < 30:
+        rows, cols = int(rng.integers(8, 420)), int(rng.integers(8, 420))
+        sigma = float(rng.choice([0.4, 0.8, 1.3, 2.0, 3.7, 6.0, 11.0, 25.0]))
+        s = O.pffft_sizing(rows, cols, sigma)
+        if s["pad"] > min(rows, cols) - 1:
+            continue
+        import blur_algorithms_amd as B
+        plans.add(tuple(B.fft_plan_radices(s["N0"])))
+        plans.add(tuple(B.fft_plan_radices(s["N1"])))
+        img = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+        quirk = bool(done % 2)
+        want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk, want_planes=True)
+        got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, nyquist_quirk=quirk).cpu().numpy()
+        assert_u8_parity(got, want, planes)
+        done += 1
+    assert len(plans) >= 8
+
+
+def test_tiny_sigma_is_the_identity_without_the_quirk(ctx):
+    """sigma 0.3 -> a one-tap window (pad 0): the blur is the identity; with the quirk on, the
+    reference adds its Nyquist checkerboard even here (Source.cpp:420-425)"""
+    torch = _torch()
+    from oracle import oracle as O
+    assert O.gaussian_window(0.3) == 1
+    img = _rand_img(40, 56, 5)
+    t = torch.from_numpy(img).cuda()
+    assert np.array_equal(ctx.pffft_(t, 0.3, out=torch.empty_like(t), nyquist_quirk=False).cpu().numpy(), img)
+    want, planes = O.pffft_blur_u8c3_f64(img, 0.3, True, want_planes=True)
+    assert_u8_parity(ctx.pffft_(t, 0.3, out=torch.empty_like(t)).cpu().numpy(), want, planes)
+
+
+def test_two_contexts_and_streams_do_not_interfere(ctx):
+    torch = _torch()
+    import blur_algorithms_amd as B
+    other = B.BlurContext(0)
+    a = torch.from_numpy(_rand_img(200, 300, 1)).cuda()
+    b = torch.from_numpy(_rand_img(200, 300, 2)).cuda()
+    ra = ctx.pffft_(a, 5.0, out=torch.empty_like(a))
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        rb = other.pffft_(b, 9.0, out=torch.empty_like(b))
+    s.synchronize()
+    torch.cuda.synchronize()
+    assert torch.equal(ra, ctx.pffft_(a, 5.0, out=torch.empty_like(a)))
+    assert torch.equal(rb, ctx.pffft_(b, 9.0, out=torch.empty_like(b)))
+    other.close()
+
+
 def test_very_tall_image_uses_planar_column_fallback(ctx):
     """rows + 2 pad -> N0 = 12000: a complex line plus the u8 pixel stage exceed LDS, the engine
     falls back to float planes + interleave (the reference's largest benchmark image is this tall)"""
