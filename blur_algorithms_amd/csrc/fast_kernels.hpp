@@ -26,6 +26,9 @@
 #ifndef FK_ROW_MID_REGS
 #define FK_ROW_MID_REGS 0           // 1: row kernel keeps the middle-pass multipliers of its butterflies in registers
 #endif
+#ifndef FK_ROW_PREFETCH
+#define FK_ROW_PREFETCH 0           // 1: row kernel loads the next line's pixels during the inner passes (packed 4 per register)
+#endif
 #ifndef FK_INNER_UNROLL
 #define FK_INNER_UNROLL 1           // butterflies of an inner / middle pass a thread keeps in flight together
 #endif
@@ -182,6 +185,17 @@ __device__ __forceinline__ void fk_inner_passes(float2* z, int zs, const float2*
         fk_inner_pass<PL, I, C, T, INV>(z, zs, twl);
         __syncthreads();
         fk_inner_passes<PL, (INV ? I - 1 : I + 1), C, T, INV>(z, zs, twl);
+    }
+}
+
+// inner passes I, I+-1, ..., LAST (inclusive), each followed by a workgroup barrier
+template <class PL, int I, int LAST, int C, int T, bool INV>
+__device__ __forceinline__ void fk_inner_range(float2* z, int zs, const float2* twl)
+{
+    if constexpr (I >= 1 && I <= PL::P - 2 && (INV ? I >= LAST : I <= LAST)) {
+        fk_inner_pass<PL, I, C, T, INV>(z, zs, twl);
+        __syncthreads();
+        fk_inner_range<PL, (INV ? I - 1 : I + 1), LAST, C, T, INV>(z, zs, twl);
     }
 }
 
@@ -435,6 +449,44 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
     // tables above are loaded once for many lines
     const int u_begin = static_cast<int>(static_cast<long long>(blockIdx.x) * nunits / gridDim.x);
     const int u_end = static_cast<int>(static_cast<long long>(blockIdx.x + 1) * nunits / gridDim.x);
+#if FK_ROW_PREFETCH
+    // The u8 pixels of line t+1 are loaded while line t is in its inner passes (where register
+    // pressure is lowest) and packed four to a register before the radix-R0 inverse pass, so the
+    // HBM round trip of a line's input does not stand in front of its first butterfly.
+    constexpr int IT0 = Pass0Regs<PL, T>::IT;
+    constexpr int PK = (R0 + 3) / 4;
+    uint32_t pka[IT0][PK], pkb[IT0][PK];
+    bool have_next = false;
+    auto line_ptr = [&](int uu, int cc, const uint8_t*& a, const uint8_t*& b) {
+        const int ff = uu / npairs, pp = uu - ff * npairs;
+        a = src0 + (static_cast<size_t>(ff) * rows + 2 * pp) * cols * CH + cc;
+        b = a + ((2 * pp + 1 < rows) ? static_cast<size_t>(cols) * CH : 0);
+    };
+#define FK_ROW_ISSUE(PA, PB, LA, LB)                                                        \
+    _Pragma("unroll") for (int it = 0; it < IT0; ++it) {                                    \
+        int jj = threadIdx.x + T * it;                                                      \
+        jj = jj < m0 ? jj : m0 - 1;                                                         \
+        _Pragma("unroll") for (int k = 0; k < R0; ++k) {                                    \
+            const int x = fk_reflect_src(jj + k * m0, pad, cols);                           \
+            const int xi = (x >= 0 ? x : 0) * CH;                                           \
+            LA[it][k] = (PA)[xi];                                                           \
+            LB[it][k] = (PB)[xi];                                                           \
+        }                                                                                   \
+    }
+#define FK_ROW_PACK(LA, LB)                                                                 \
+    _Pragma("unroll") for (int it = 0; it < IT0; ++it)                                      \
+        _Pragma("unroll") for (int w = 0; w < PK; ++w) {                                    \
+            uint32_t va = 0, vb = 0;                                                        \
+            _Pragma("unroll") for (int b = 0; b < 4; ++b)                                   \
+                if (4 * w + b < R0) {                                                       \
+                    va |= static_cast<uint32_t>(LA[it][4 * w + b]) << (8 * b);              \
+                    vb |= static_cast<uint32_t>(LB[it][4 * w + b]) << (8 * b);              \
+                }                                                                           \
+            pka[it][w] = va;                                                                \
+            pkb[it][w] = vb;                                                                \
+        }
+#endif
+
     for (int u = u_begin; u < u_end; ++u) {
         const int f = u / npairs, pair = u - f * npairs;
         src = src0 + static_cast<size_t>(f) * rows * cols * CH;
@@ -447,6 +499,57 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
             FK_STAMP(0);       // prologue (first line) / loop overhead
             __syncthreads();   // previous line's readers are done with z (and twl is visible)
             FK_STAMP(1);       // barrier
+#if FK_ROW_PREFETCH
+            if (!have_next) {  // first line of this workgroup: nothing was prefetched
+                uint8_t la[IT0][R0], lb[IT0][R0];
+                const uint8_t *qa, *qb;
+                line_ptr(u, c, qa, qb);
+                FK_ROW_ISSUE(qa, qb, la, lb)
+                FK_ROW_PACK(la, lb)
+            }
+#pragma unroll
+            for (int it = 0; it < IT0; ++it) {
+                const int j = threadIdx.x + T * it;
+                if (j < m0) {
+                    float2 v[R0];
+#pragma unroll
+                    for (int k = 0; k < R0; ++k) {
+                        const bool ok = fk_reflect_src(j + k * m0, pad, cols) >= 0;
+                        const float a = static_cast<float>((pka[it][k >> 2] >> (8 * (k & 3))) & 0xffu);
+                        const float b = static_cast<float>((pkb[it][k >> 2] >> (8 * (k & 3))) & 0xffu);
+                        v[k] = make_float2(ok ? a : 0.f, (ok && two) ? b : 0.f);
+                    }
+                    Bfly<R0, false>::run(v);
+                    z[PL::at(j)] = v[0];
+#pragma unroll
+                    for (int q = 1; q < R0; ++q) z[PL::at(j + q * m0)] = cmul(v[q], p0.w[it][q]);
+                }
+            }
+            FK_STAMP(2);
+            __syncthreads();
+            FK_STAMP(3);
+            // first forward inner pass (the register-hungry one), THEN issue the next line's pixel
+            // loads: they are in flight across the light passes and packed before the last
+            // inverse inner pass
+            fk_inner_range<PL, 1, 1, 1, T, false>(z, 0, twl);
+            uint8_t na[IT0][R0], nb[IT0][R0];
+            {
+                const int nu = c + 1 < CH ? u : u + 1, nc = c + 1 < CH ? c + 1 : 0;
+                have_next = nu < u_end;
+                if (have_next) {
+                    const uint8_t *qa, *qb;
+                    line_ptr(nu, nc, qa, qb);
+                    FK_ROW_ISSUE(qa, qb, na, nb)
+                }
+            }
+            fk_inner_range<PL, 2, P - 2, 1, T, false>(z, 0, twl);
+            fk_mid_lds<PL, T, 1>(z, 0, mid_tab);
+            __syncthreads();
+            fk_inner_range<PL, P - 2, 2, 1, T, true>(z, 0, twl);
+            if (have_next) { FK_ROW_PACK(na, nb) }
+            fk_inner_range<PL, 1, 1, 1, T, true>(z, 0, twl);
+            FK_STAMP(4);
+#else
             // ---- pass 0: global u8 -> butterfly -> twiddle -> LDS
 #pragma unroll
             for (int it = 0; it < Pass0Regs<PL, T>::IT; ++it) {
@@ -481,7 +584,8 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
             FK_STAMP(2);       // pass 0 incl. global loads
             __syncthreads();
             FK_STAMP(3);       // barrier
-#ifndef FK_ABL_NOMIDDLE  // ablation build: only pass 0 and its inverse
+#endif
+#if !defined(FK_ABL_NOMIDDLE) && !FK_ROW_PREFETCH  // ablation build: only pass 0 and its inverse
 #if FK_WAVE_LOCAL_ROW
             fk_inner_section_wave<PL, 1, T>(z, 0, twl, mid_tab);
             __syncthreads();
