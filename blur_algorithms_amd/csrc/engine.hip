@@ -74,14 +74,14 @@ __global__ __launch_bounds__(kThreads) void rowpass_kernel(const InT* __restrict
     const InT* row_a = src + (static_cast<size_t>(r0) * cols) * CH + c;
     const InT* row_b = src + (static_cast<size_t>(r0 + (two ? 1 : 0)) * cols) * CH + c;
 
+    // unconditional loads (clamped index, value masked afterwards): a load under a branch costs one
+    // memory round trip per iteration, unconditional ones overlap across the unrolled iterations
+#pragma unroll 8
     for (int p = threadIdx.x; p < n; p += kThreads) {
         const int x = reflect_src(p, pad, cols);
-        float2 v = make_float2(0.f, 0.f);
-        if (x >= 0) {
-            v.x = load_px(row_a + static_cast<size_t>(x) * CH);
-            if (two) v.y = load_px(row_b + static_cast<size_t>(x) * CH);
-        }
-        z[phys(p)] = v;
+        const size_t xi = static_cast<size_t>(x >= 0 ? x : 0) * CH;
+        const float a = load_px(row_a + xi), b = load_px(row_b + xi);
+        z[phys(p)] = make_float2(x >= 0 ? a : 0.f, (x >= 0 && two) ? b : 0.f);
     }
     __syncthreads();
     fftconv_lines<1>(z, 0, plan, tw, mperm);
@@ -117,17 +117,14 @@ __global__ __launch_bounds__(kThreads) void colpass_kernel(const float* __restri
     for (int c = 0; c < CH; ++c) {
         const float* plane = planes + static_cast<size_t>(c) * rows * cols;
         // gather the strip: position p of line l  <-  plane[reflect(p)][x0 + 2l, x0 + 2l + 1]
+#pragma unroll 4
         for (int idx = threadIdx.x; idx < n * C; idx += kThreads) {
             const int p = idx / C, l = idx - p * C;
             const int r = reflect_src(p, pad, rows);
-            float2 v = make_float2(0.f, 0.f);
-            if (r >= 0) {
-                const int col = x0 + 2 * l;
-                const float* s = plane + static_cast<size_t>(r) * cols + col;
-                if (col < cols) v.x = s[0];
-                if (col + 1 < cols) v.y = s[1];
-            }
-            z[l * zs + phys(p)] = v;
+            const int col = x0 + 2 * l;
+            const float* s = plane + static_cast<size_t>(r >= 0 ? r : 0) * cols;
+            const float a = s[col < cols ? col : cols - 1], b = s[col + 1 < cols ? col + 1 : cols - 1];   // unconditional
+            z[l * zs + phys(p)] = make_float2((r >= 0 && col < cols) ? a : 0.f, (r >= 0 && col + 1 < cols) ? b : 0.f);
         }
         __syncthreads();
         fftconv_lines<C>(z, zs, plan, tw, mperm);
