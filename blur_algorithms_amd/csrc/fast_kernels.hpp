@@ -35,6 +35,9 @@
 #ifndef FK_HOIST_MAX_R
 #define FK_HOIST_MAX_R 16           // inner passes up to this radix read their twiddles up front
 #endif
+#ifndef FK_COL_DEFER_WRITEOUT
+#define FK_COL_DEFER_WRITEOUT 0     // 1: spread a strip's pixel stores over the next strip's first channel (measured: no gain, the stores stall their wave wherever they are issued)
+#endif
 #ifndef FK_COL_PREFETCH
 #define FK_COL_PREFETCH 1           // column kernel, strip layout: load the next task's strip into registers during the passes
 #endif
@@ -741,6 +744,27 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
         }
     };
 
+    // Deferred write-out: the 24-byte row segments of a finished strip cost one L2 request each
+    // (the slow part is the texture-address unit, not bandwidth), so instead of issuing them in
+    // one burst they are issued in three parts between the phases of the next strip's first
+    // channel, where they overlap with LDS and VALU work.  The stage is only rewritten by that
+    // channel's last pass, after part 2.
+    constexpr int RQ8 = (G * CH) / 8;
+    int pend_x0 = -1;
+    uint8_t* pend_dst = nullptr;
+    auto writeout_part = [&](int part) {
+        if (pend_x0 < 0) return;
+        const int total = rows * RQ8, per = (total + 2) / 3;
+        const int begin = part * per, end = begin + per < total ? begin + per : total;
+        const uint2* s64 = reinterpret_cast<const uint2*>(stage);
+        FK_UNROLL(4)
+        for (int idx = begin + static_cast<int>(threadIdx.x); idx < end; idx += T) {
+            const int r = idx / RQ8, d = idx - r * RQ8;
+            reinterpret_cast<uint2*>(pend_dst + (static_cast<size_t>(r) * cols + pend_x0) * CH)[d] = s64[idx];
+        }
+        if (part == 2) pend_x0 = -1;
+    };
+
     for (int u = u_begin + lane_in_xcd; u < u_end; u += wg_in_xcd) {
         const int f = u / nstrips, strip = u - f * nstrips;
         planes = planes0 + static_cast<size_t>(f) * plane_elems * CH;
@@ -784,6 +808,7 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
                 pf_valid = nu < u_end;
                 if (pf_valid) issue_gather(nu, nch);
             }
+            if (FK_COL_DEFER_WRITEOUT && ch == 0) writeout_part(0);
             // ---- pass 0 (register twiddles)
             if (p0_active) {
 #pragma unroll
@@ -806,8 +831,10 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
             }
             __syncthreads();
             FK_STAMP(2);       // barrier + pass 0 + barrier
+            if (FK_COL_DEFER_WRITEOUT && ch == 0) writeout_part(1);
             if constexpr (WL) {
                 fk_inner_section_wave<PL, C, T>(z, zs, twl, mpl);
+                if (FK_COL_DEFER_WRITEOUT && ch == 0) writeout_part(2);
                 __syncthreads();
                 FK_STAMP(4);   // wave-local inner section + barrier
             } else {
@@ -816,6 +843,7 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
             fk_mid_lds<PL, T, C>(z, zs, mpl);
             __syncthreads();
             FK_STAMP(5);       // fused middle
+            if (FK_COL_DEFER_WRITEOUT && ch == 0) { writeout_part(2); __syncthreads(); }
             fk_inner_passes<PL, P - 2, C, T, true>(z, zs, twl);
             FK_STAMP(6);       // inverse inner passes
             }
@@ -851,7 +879,10 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
         __syncthreads();
         // ---- write the strip as whole pixels: G*CH contiguous bytes per image row
         constexpr int RB = G * CH;
-        if (x0 + G <= cols && ((cols * CH) & 7) == 0 && (RB & 7) == 0) {
+        if (FK_COL_DEFER_WRITEOUT && x0 + G <= cols && ((cols * CH) & 7) == 0 && (RB & 7) == 0) {
+            pend_x0 = x0;                  // issued during the next strip (or flushed after the loop)
+            pend_dst = dst;
+        } else if (x0 + G <= cols && ((cols * CH) & 7) == 0 && (RB & 7) == 0) {
             // 8-byte stores: three per image row of the strip
             constexpr int RQ = RB / 8;
             const uint2* s64 = reinterpret_cast<const uint2*>(stage);
@@ -877,6 +908,7 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
             }
         }
     }
+    for (int part = 0; part < 3; ++part) writeout_part(part);     // the last strip of this workgroup
 #ifdef FK_STAMPS
     FK_STAMP(0);
     if (threadIdx.x == 0) {
