@@ -29,6 +29,12 @@
 #ifndef FK_ROW_PREFETCH
 #define FK_ROW_PREFETCH 0           // 1: row kernel loads the next line's pixels during the inner passes (packed 4 per register)
 #endif
+#ifndef FK_INNER_BATCH
+#define FK_INNER_BATCH 2            // butterflies of one thread whose LDS reads are issued together (inner passes)
+#endif
+#ifndef FK_BATCH_MAX_R
+#define FK_BATCH_MAX_R 5            // largest radix that is batched (radix 10 in pairs spills at the 168-VGPR budget)
+#endif
 #ifndef FK_INNER_UNROLL
 #define FK_INNER_UNROLL 1           // butterflies of an inner / middle pass a thread keeps in flight together
 #endif
@@ -129,52 +135,59 @@ __device__ __forceinline__ int fk_reflect_src(int p, int pad, int len)
 }
 
 // ---- inner passes on LDS, flattened over (line, butterfly) ----------------------------------
+// FK_INNER_BATCH butterflies of a thread are read together (data and twiddles of all of them
+// before the first use), so that one LDS latency is paid per batch and the second butterfly's
+// reads are in flight while the first is computed.  Radices above FK_HOIST_MAX_R keep batch 1 and
+// read their twiddles where they are used (register pressure).
 template <class PL, int I, int C, int T, bool INV>
 __device__ __forceinline__ void fk_inner_pass(float2* z, int zs, const float2* twl)
 {
     constexpr int R = PL::R[I], m = PL::m(I), nb = PL::nb(I), total = nb * C;
     constexpr int off = PL::tw_off(I) - PL::lds_tw_begin();
-    FK_UNROLL(FK_INNER_UNROLL)
-    for (int g = threadIdx.x; g < total; g += T) {
-        const int c = g / nb, b = g - c * nb;
-        const int blk = b / m, j = b - blk * m;
-        const int base = blk * (R * m) + j;
-        float2* zc = z + c * zs;
-        // Radices up to FK_HOIST_MAX_R: issue every LDS read (data and twiddles) before the first
-        // use (one latency, not R).  Larger radices would spill, there the twiddles are read
-        // where they are used.
-        float2 v[R];
+    constexpr bool hoist = R <= FK_HOIST_MAX_R;
+    constexpr int B = (hoist && R <= FK_BATCH_MAX_R && total > T) ? FK_INNER_BATCH : 1;
+#pragma unroll 1
+    for (int g0 = threadIdx.x; g0 < total; g0 += T * B) {
+        float2 v[B][R], w[B][R];
+        int base[B], jj[B];
+        bool act[B];
+        float2* zc[B];
 #pragma unroll
-        for (int k = 0; k < R; ++k) v[k] = zc[PL::at(base + k * m)];
-        if constexpr (R <= FK_HOIST_MAX_R) {
-            float2 w[R];
+        for (int bi = 0; bi < B; ++bi) {
+            const int g = g0 + bi * T;
+            act[bi] = g < total;
+            const int gg = act[bi] ? g : total - 1;
+            const int c = gg / nb, b = gg - c * nb;
+            const int blk = b / m;
+            jj[bi] = b - blk * m;
+            base[bi] = blk * (R * m) + jj[bi];
+            zc[bi] = z + c * zs;
 #pragma unroll
-            for (int q = 1; q < R; ++q) w[q] = twl[off + (q - 1) * m + j];
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!INV) {
-                Bfly<R, false>::run(v);
-                zc[PL::at(base)] = v[0];
+            for (int k = 0; k < R; ++k) v[bi][k] = zc[bi][PL::at(base[bi] + k * m)];
+            if constexpr (hoist) {
 #pragma unroll
-                for (int q = 1; q < R; ++q) zc[PL::at(base + q * m)] = cmul(v[q], w[q]);
-            } else {
-#pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], w[q]);
-                Bfly<R, true>::run(v);
-#pragma unroll
-                for (int k = 0; k < R; ++k) zc[PL::at(base + k * m)] = v[k];
+                for (int q = 1; q < R; ++q) w[bi][q] = twl[off + (q - 1) * m + jj[bi]];
             }
-        } else {
-            if constexpr (!INV) {
-                Bfly<R, false>::run(v);
-                zc[PL::at(base)] = v[0];
+        }
+        if constexpr (hoist) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 1; q < R; ++q) zc[PL::at(base + q * m)] = cmul(v[q], twl[off + (q - 1) * m + j]);
+        for (int bi = 0; bi < B; ++bi) {
+            if constexpr (!INV) {
+                Bfly<R, false>::run(v[bi]);
+                if (act[bi]) {
+                    zc[bi][PL::at(base[bi])] = v[bi][0];
+#pragma unroll
+                    for (int q = 1; q < R; ++q)
+                        zc[bi][PL::at(base[bi] + q * m)] = cmul(v[bi][q], hoist ? w[bi][q] : twl[off + (q - 1) * m + jj[bi]]);
+                }
             } else {
 #pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], twl[off + (q - 1) * m + j]);
-                Bfly<R, true>::run(v);
+                for (int q = 1; q < R; ++q) v[bi][q] = cmulc(v[bi][q], hoist ? w[bi][q] : twl[off + (q - 1) * m + jj[bi]]);
+                Bfly<R, true>::run(v[bi]);
+                if (act[bi]) {
 #pragma unroll
-                for (int k = 0; k < R; ++k) zc[PL::at(base + k * m)] = v[k];
+                    for (int k = 0; k < R; ++k) zc[bi][PL::at(base[bi] + k * m)] = v[bi][k];
+                }
             }
         }
     }
@@ -248,23 +261,39 @@ template <class PL, int T, int C>
 __device__ __forceinline__ void fk_mid_lds(float2* z, int zs, const float* __restrict__ mpl)
 {
     constexpr int R = PL::R[PL::P - 1], nb = PL::nb(PL::P - 1), total = nb * C;
-    FK_UNROLL(FK_INNER_UNROLL)
-    for (int g = threadIdx.x; g < total; g += T) {
-        const int c = g / nb, b = g - c * nb;
-        float2* zc = z + c * zs;
-        float2 v[R];
-        float mm[R];
+    constexpr int B = (R <= FK_BATCH_MAX_R && total > T) ? FK_INNER_BATCH : 1;
+#pragma unroll 1
+    for (int g0 = threadIdx.x; g0 < total; g0 += T * B) {
+        float2 v[B][R];
+        float mm[B][R];
+        float2* zc[B];
+        int base[B];
+        bool act[B];
 #pragma unroll
-        for (int k = 0; k < R; ++k) v[k] = zc[PL::at(b * R + k)];
+        for (int bi = 0; bi < B; ++bi) {
+            const int g = g0 + bi * T;
+            act[bi] = g < total;
+            const int gg = act[bi] ? g : total - 1;
+            const int c = gg / nb, b = gg - c * nb;
+            zc[bi] = z + c * zs;
+            base[bi] = b * R;
 #pragma unroll
-        for (int q = 0; q < R; ++q) mm[q] = mpl[b * R + q];
+            for (int k = 0; k < R; ++k) v[bi][k] = zc[bi][PL::at(base[bi] + k)];
+#pragma unroll
+            for (int q = 0; q < R; ++q) mm[bi][q] = mpl[base[bi] + q];
+        }
         if constexpr (R <= FK_HOIST_MAX_R) __builtin_amdgcn_sched_barrier(0);
-        Bfly<R, false>::run(v);
 #pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mm[q]);
-        Bfly<R, true>::run(v);
+        for (int bi = 0; bi < B; ++bi) {
+            Bfly<R, false>::run(v[bi]);
 #pragma unroll
-        for (int k = 0; k < R; ++k) zc[PL::at(b * R + k)] = v[k];
+            for (int q = 0; q < R; ++q) v[bi][q] = cscale(v[bi][q], mm[bi][q]);
+            Bfly<R, true>::run(v[bi]);
+            if (act[bi]) {
+#pragma unroll
+                for (int k = 0; k < R; ++k) zc[bi][PL::at(base[bi] + k)] = v[bi][k];
+            }
+        }
     }
 }
 
@@ -919,8 +948,12 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
 }
 
 // ---- launchers ---------------------------------------------------------------------------
+#ifndef FK_ROW_LDS_EXTRA
+#define FK_ROW_LDS_EXTRA 0          // diagnostic: extra LDS bytes per row workgroup (forces fewer workgroups per CU)
+#endif
 template <class PL> size_t fk_row_lds()
 {
+    if (FK_ROW_LDS_EXTRA) return FK_ROW_LDS_EXTRA;
     return (static_cast<size_t>(PL::zs()) + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) +
            ((FK_ROW_MID_GLOBAL || FK_ROW_MID_REGS) ? 0 : static_cast<size_t>(PL::N) * sizeof(float));
 }

@@ -13,7 +13,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 lib = _lib.load()
 lib.blur_debug_read_stamps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
-nblk = 1080
+nblk = 4096
 buf = np.zeros(nblk * 8, np.uint64)
 for n_fft, names in ((4000, ["prologue/loop", "barrier A", "pass0+gload", "barrier B", "fwd inner", "mid", "inv inner", "inv pass0+store"]),
                      (2304, ["prologue/loop/writeout", "gather+barriers", "pass0", "last writeout", "fwd inner", "mid", "inv inner", "inv pass0+stage"])):
