@@ -88,6 +88,8 @@ def main():
     ap.add_argument("--sigma", type=float, default=20.0)
     ap.add_argument("--col-group", type=int, default=0)
     ap.add_argument("--frames-per-launch", type=int, default=0, help="0 = the library's choice")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
+    ap.add_argument("--all-on-device0", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -103,10 +105,15 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.all_on_device0:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.dist_backend)
 
     rows, cols, sigma, F = args.rows, args.cols, args.sigma, args.frames
     g = torch.Generator(device=dev)
@@ -138,7 +145,7 @@ def main():
     tm = ctx.timing(reset=True) if not args.no_events else None
     ctx.timing_enable(False)
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())

@@ -299,9 +299,11 @@ BLUR_HD void run_pass(int kind, int R, float2* z, int zs, int n, int m, const fl
     case 5: run_pass_r<5, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
     case 6: run_pass_r<6, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
     case 8: run_pass_r<8, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
+#if !defined(BLUR_GENERIC_MAX_RADIX) || BLUR_GENERIC_MAX_RADIX > 8
     case 9: run_pass_r<9, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
     case 10: run_pass_r<10, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
     case 16: run_pass_r<16, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
+#endif
 #ifdef BLUR_ENGINE_ALL_RADICES   // CPU harness only: the generic kernels never plan these
     case 12: run_pass_r<12, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;
     case 15: run_pass_r<15, C>(kind, z, zs, n, m, tw, mperm, tid, nthreads); break;

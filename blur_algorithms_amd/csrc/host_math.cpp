@@ -133,8 +133,30 @@ void kernel_multipliers_from_array(const float* k, int n, float* m)
     }
 }
 
+#ifndef BLUR_GENERIC_MAX_RADIX
+#define BLUR_GENERIC_MAX_RADIX 16   // largest radix of the run-time plans (the generic kernels' switch must match)
+#endif
+
 static void choose_radices(int n, std::vector<int>& out)
 {
+#if BLUR_GENERIC_MAX_RADIX <= 8
+    {   // small-radix plans: more passes, far fewer registers in the run-time-planned kernels
+        int c2 = 0, c3 = 0, c5 = 0, r = n;
+        while (r % 2 == 0) { r /= 2; ++c2; }
+        while (r % 3 == 0) { r /= 3; ++c3; }
+        while (r % 5 == 0) { r /= 5; ++c5; }
+        out.clear();
+        if (r != 1) return;
+        while (c3 > 0 && c2 > 0 && c2 % 3 != 0) { out.push_back(6); --c3; --c2; }
+        while (c3 > 0) { out.push_back(3); --c3; }
+        while (c5 > 0) { out.push_back(5); --c5; }
+        while (c2 >= 3) { out.push_back(8); c2 -= 3; }
+        if (c2 == 2) out.push_back(4);
+        if (c2 == 1) out.push_back(2);
+        std::sort(out.begin(), out.end(), std::greater<int>());
+        return;
+    }
+#endif
     // Few LDS round trips matter more than flops: take the largest radix first.
     // Supported butterflies: 16 10 9 8 6 5 4 3 2.
     int c2 = 0, c3 = 0, c5 = 0, r = n;
