@@ -766,7 +766,14 @@ int blur_ctx_destroy(blur_ctx* ctx)
 int blur_ctx_set_stream(blur_ctx* ctx, void* hip_stream)
 {
     if (!ctx) return BLUR_ERR_INVALID;
-    ctx->stream = static_cast<hipStream_t>(hip_stream);
+    hipStream_t next = static_cast<hipStream_t>(hip_stream);
+    if (next != ctx->stream) {
+        // the workspace and the cached tables are shared: work queued on the old stream must be
+        // finished before another stream may touch them
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->stream = next;
+    }
     return BLUR_OK;
 }
 

@@ -90,7 +90,8 @@ int blur_fft_plan_radices(int n, int* radices);
    Source.cpp:477-478,565-566, which the reference rebuilds on every call.) */
 int blur_ctx_create(blur_ctx** out, int device);
 int blur_ctx_destroy(blur_ctx* ctx);
-/* hipStream_t to launch on (NULL = the default stream) */
+/* hipStream_t to launch on (NULL = the default stream).  Switching to a different stream first
+   waits for the work queued on the previous one (the workspace is shared). */
 int blur_ctx_set_stream(blur_ctx* ctx, void* hip_stream);
 int blur_ctx_synchronize(blur_ctx* ctx);
 /* message of the last failing call on this ctx ("" if none); ctx may be NULL for
