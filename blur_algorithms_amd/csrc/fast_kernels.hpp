@@ -29,6 +29,9 @@
 #ifndef FK_ROW_PREFETCH
 #define FK_ROW_PREFETCH 0           // 1: row kernel loads the next line's pixels during the inner passes (packed 4 per register)
 #endif
+#ifndef FK_ROW_TW0_RELOAD
+#define FK_ROW_TW0_RELOAD 0         // 1: row kernel re-reads pass 0's twiddles from global (L1/L2) in pass 0 and its inverse
+#endif                               //    instead of holding them in registers across the inner passes
 #ifndef FK_INNER_BATCH
 #define FK_INNER_BATCH 2            // butterflies of one thread whose LDS reads are issued together (inner passes)
 #endif
@@ -583,6 +586,9 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
             FK_STAMP(4);
 #else
             // ---- pass 0: global u8 -> butterfly -> twiddle -> LDS
+#if FK_ROW_TW0_RELOAD
+            p0.load(tw, threadIdx.x);
+#endif
 #pragma unroll
             for (int it = 0; it < Pass0Regs<PL, T>::IT; ++it) {
                 const int j = threadIdx.x + T * it;
@@ -635,6 +641,9 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
             fk_inner_passes<PL, P - 2, 1, T, true>(z, 0, twl);
             FK_STAMP(6);       // inverse inner passes + barriers
 #endif
+#endif
+#if FK_ROW_TW0_RELOAD
+            p0.load(tw, threadIdx.x);
 #endif
             // ---- inverse pass 0: LDS -> conj twiddle -> butterfly -> cropped float rows
             float* out_a = planes + static_cast<size_t>(c) * plane_elems + (tile_shift ? static_cast<size_t>(pair) * (2 * tile_w) : static_cast<size_t>(r0) * cols);
