@@ -95,6 +95,19 @@ def test_device_fft_arithmetic_on_cpu(engine_host_check):
     assert out.returncode == 0, out.stdout + out.stderr
 
 
+def test_fastboxblur_include_path_shim_compiles(tmp_path):
+    """a translation unit that includes "FastBoxBlur/fast_box_blur.h" the way Source.cpp does (line 7)"""
+    src = tmp_path / "tu.cpp"
+    src.write_text('#include "FastBoxBlur/fast_box_blur.h"\n'
+                   'int main() { float a[6] = {0, 1, 2, 3, 4, 5}, b[6]; flip_block<float, 1>(a, b, 3, 2); '
+                   'void (*f)(uint8_t*, int, int, int, int, int, blur_ctx*) = &fastboxblur; return (b[1] == 3.f && f) ? 0 : 1; }\n')
+    exe = str(tmp_path / "tu")
+    subprocess.check_call(["g++", "-std=c++17", "-I" + os.path.join(ROOT, "include", "compat"), "-I" + os.path.join(ROOT, "include"),
+                           str(src), "-L" + os.path.dirname(B.LIB_PATH), "-lblur_amd", "-Wl,-rpath," + os.path.dirname(B.LIB_PATH),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    assert subprocess.run([exe]).returncode == 0
+
+
 def test_cpp_header_with_reference_names():
     exe = os.path.join(ROOT, "tests", "cpp", "surface_check")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-fopenmp", "-I" + os.path.join(ROOT, "include"),
