@@ -753,7 +753,11 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
             int idx = threadIdx.x + T * k;
             idx = idx < n_items ? idx : n_items - 1;
             const int q = idx / C, l = idx - q * C;
+#ifdef FK_ABL_NOLOAD
+            pf[k] = make_float4(q * 0.5f, l * 1.f, q * 0.25f, 3.f);
+#else
             pf[k] = *reinterpret_cast<const float4*>(sb + static_cast<size_t>(q) * (2 * G) + 4 * l);
+#endif
         }
     };
     auto commit_gather = [&](int xx0) {
@@ -928,7 +932,11 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
             for (int idx = threadIdx.x; idx < rows * RQ; idx += T) {
                 const int r = idx / RQ, d = idx - r * RQ;
                 uint2* o = reinterpret_cast<uint2*>(dst + (static_cast<size_t>(r) * cols + x0) * CH);
+#ifdef FK_ABL_NOSTORE
+                asm volatile("" ::"v"(s64[idx].x), "v"(s64[idx].y), "v"(o));
+#else
                 o[d] = s64[idx];
+#endif
             }
         } else if (x0 + G <= cols && ((cols * CH) & 3) == 0 && (RB & 3) == 0) {
             constexpr int RD = RB / 4;
