@@ -36,8 +36,10 @@ def ctx():
 # float planes: |engine - float64 oracle| <= FLOAT_TOL grey levels (inputs in [0,255]);
 # u8 output: equal to the oracle's rounding except where the oracle's own value lies within
 # TIE_TOL of a rounding boundary (k + 0.5), and then off by exactly one.
-FLOAT_TOL = 2.5e-4
-TIE_TOL = 5e-4
+# Observed on MI355X (tools/float_error.py): max float error 4.6e-5 .. 7.6e-5 grey levels, i.e. 3-5 float32 ULP at
+# the magnitudes involved (ULP(128..255) = 1.5e-5); the tolerances are twice the worst observation.
+FLOAT_TOL = 1.5e-4
+TIE_TOL = 1.5e-4
 
 
 def assert_u8_parity(got, want_u8, want_planes):
