@@ -88,6 +88,9 @@ def main():
     ap.add_argument("--sigma", type=float, default=20.0)
     ap.add_argument("--col-group", type=int, default=0)
     ap.add_argument("--frames-per-launch", type=int, default=0, help="0 = the library's choice")
+    ap.add_argument("--data", default="synthetic", choices=["synthetic", "natural"],
+                    help="synthetic: i.i.d. uniform u8 (worst case for round-off and for DVFS); natural: a committed crop of the "
+                         "reference's test_images tiled to the frame size")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -118,7 +121,14 @@ def main():
     rows, cols, sigma, F = args.rows, args.cols, args.sigma, args.frames
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED0000 + rank)
-    frames = torch.randint(0, 256, (F, rows, cols, 3), dtype=torch.uint8, device=dev, generator=g)
+    if args.data == "synthetic":
+        frames = torch.randint(0, 256, (F, rows, cols, 3), dtype=torch.uint8, device=dev, generator=g)
+    else:
+        import numpy as np
+        tile = np.load(os.path.join(ROOT, "tests", "golden", "img_collage_top.npz"))["src"]
+        reps = (-(-rows // tile.shape[0]), -(-cols // tile.shape[1]), 1)
+        one = torch.from_numpy(np.ascontiguousarray(np.tile(tile, reps)[:rows, :cols])).to(dev)
+        frames = torch.stack([torch.roll(one, shifts=(17 * i, 31 * i), dims=(0, 1)) for i in range(F)]).contiguous()
     out = torch.empty_like(frames)
     ctx = B.BlurContext(local)
 
@@ -165,7 +175,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": args.data,
             "config": {
                 "workload": "%dx%d RGB u8 frames, sigma=%g (kSize %d), FFT row/col lengths %d/%d, %d frames per GPU per step, device-resident"
                             % (cols, rows, sigma, B.pffft_sizing(rows, cols, sigma)["kSize"],
