@@ -151,6 +151,13 @@ class BlurContext:
         """
         o = self._opts(nyquist_quirk, col_group, force_generic, frames_per_launch, row_major_planes)
         if isinstance(image, np.ndarray):
+            if (image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3 and not image.flags["C_CONTIGUOUS"]
+                    and image.strides[2] == 1 and image.strides[1] == 3 and image.strides[0] >= 3 * image.shape[1]):
+                # a view with padded rows (a cv::Mat ROI): pitched entry point, no host-side repacking
+                res = np.empty(image.shape, np.uint8)
+                self._check(self._lib.blur_gaussian_u8c3_host_pitched(self._h, image.ctypes.data, image.strides[0], res.ctypes.data,
+                                                                      res.strides[0], image.shape[0], image.shape[1], float(sigma), C.byref(o)))
+                return res
             a = np.ascontiguousarray(image, np.uint8)
             if a.ndim != 3 or a.shape[2] != 3:
                 raise ValueError("expected a uint8 image of shape [rows, cols, 3]")

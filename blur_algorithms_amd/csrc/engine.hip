@@ -925,6 +925,27 @@ int blur_gaussian_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int
     return rc;
 }
 
+int blur_gaussian_u8c3_host_pitched(blur_ctx* ctx, const uint8_t* src, size_t src_pitch, uint8_t* dst, size_t dst_pitch,
+                                    int rows, int cols, double sigma, const blur_opts* opts)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    const size_t row_bytes = static_cast<size_t>(cols) * 3;
+    if (!src || !dst || rows <= 0 || cols <= 0 || src_pitch < row_bytes || dst_pitch < row_bytes)
+        return fail(ctx, BLUR_ERR_INVALID, "null image, non-positive size or pitch shorter than a row");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint8_t* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), row_bytes * rows));
+    int rc = BLUR_OK;
+    // the rows are packed on the way in and unpacked on the way out (cv::Mat::step of a ROI or padded Mat)
+    hipError_t e = hipMemcpy2DAsync(d, row_bytes, src, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) rc = blur_gaussian_u8c3_dev(ctx, d, d, rows, cols, sigma, opts);
+    if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpy2DAsync(dst, dst_pitch, d, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d);
+    if (e != hipSuccess) { ctx->err = std::string("host blur (pitched): ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
+    return rc;
+}
+
 int blur_gaussian_f32c1_host(blur_ctx* ctx, const float* src, float* dst, int rows, int cols, double sigma, const blur_opts* opts)
 {
     if (!ctx) return BLUR_ERR_INVALID;

@@ -127,6 +127,10 @@ int blur_gaussian_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst,
                             int rows, int cols, double sigma, const blur_opts* opts);
 int blur_gaussian_f32c1_host(blur_ctx* ctx, const float* src, float* dst,
                              int rows, int cols, double sigma, const blur_opts* opts);
+/* the same for images whose rows are src_pitch / dst_pitch BYTES apart (cv::Mat::step of a ROI or
+   of a padded Mat; pffft_() itself assumes image.data is continuous, Source.cpp:459-461) */
+int blur_gaussian_u8c3_host_pitched(blur_ctx* ctx, const uint8_t* src, size_t src_pitch, uint8_t* dst, size_t dst_pitch,
+                                    int rows, int cols, double sigma, const blur_opts* opts);
 
 /* Row pass only (Source.cpp:520-537): u8c3 frame -> three float planes, row-major
    (what `resf` holds at Source.cpp:536).  d_planes: 3*rows*cols floats.  For tests. */

@@ -152,6 +152,16 @@ def test_host_entry_point_matches_device(ctx):
     assert np.array_equal(dev, host)
 
 
+def test_pitched_host_image_like_a_cv_mat_roi(ctx):
+    """rows that are farther apart than cols*3 bytes (a region of interest of a larger image)"""
+    big = _rand_img(140, 200, 6)
+    roi = big[20:110, 30:170]                      # 90 x 140 view, row pitch 600 bytes
+    assert not roi.flags["C_CONTIGUOUS"]
+    got = ctx.pffft_(roi, 6.0)
+    want = ctx.pffft_(np.ascontiguousarray(roi), 6.0)
+    assert np.array_equal(got, want)
+
+
 def test_batch_equals_single_frames(ctx):
     torch = _torch()
     frames = torch.from_numpy(np.stack([_rand_img(72, 100, s) for s in range(4)])).cuda()
