@@ -178,6 +178,19 @@ class BlurContext:
         self._check(self._lib.blur_gaussian_u8c3_batch_dev(self._h, t.data_ptr(), dst.data_ptr(), n, rows, cols, float(sigma), C.byref(o)))
         return dst
 
+    def pocketfft_1D(self, image, sigma, out=None, **kw):
+        """pocketfft_1D(image, sigma) (Source.cpp:280-392): the same 1D tiles as pffft_() with N/2+1 bins and the
+        true Nyquist multiplier (:362,:378) -- this engine's `nyquist_quirk = 0` mode."""
+        return self.pffft_(image, sigma, out=out, nyquist_quirk=False, **kw)
+
+    def pocketfft_2D(self, image, sigma, out=None, **kw):
+        """pocketfft_2D(image, sigma) (Source.cpp:143-277): Reflect_101 of the whole image, 2D r2c, separable
+        multiply, c2r, crop.  Inside the crop that is the linear convolution of the reflect-101 extended image with
+        the same taps (every border is >= the kernel half width, so neither the wrap-around nor the extra
+        transform-size padding reaches a kept pixel): the 1D-tiled engine computes it without materialising the
+        padded image.  tests/ compare with the scipy.fft (pocketfft) restatement of the 2D path."""
+        return self.pffft_(image, sigma, out=out, nyquist_quirk=False, **kw)
+
     def pffft_boxblur(self, image, nsmooth, out=None, nyquist_quirk=True):
         """pffft_() compiled with `#define boxblur`: FFT-domain tent kernel (Source.cpp:437-442,468-472);
         uint8 CUDA tensor [rows, cols, 3]"""

@@ -15,6 +15,7 @@
 //   flip_block<T,C>(in, out, w, h)                          call sites Source.cpp:540,562
 //   fastboxblur(in, w, h, channels, ksize, passes)          call site  Source.cpp:587
 //   pffft_(image, sigma)                                    Source.cpp:429-570
+//   pocketfft_1D(image, sigma) / pocketfft_2D(image, sigma) Source.cpp:280-392 / 143-277 (same engine, no Nyquist quirk)
 //
 // Everything lives in namespace blur_amd::compat; define BLUR_AMD_GLOBAL_NAMES before including
 // to also get the names in the global namespace, as the reference has them.
@@ -180,6 +181,22 @@ template <class Mat, class = decltype(std::declval<Mat&>().size[0])> void pffft_
     pffft_(reinterpret_cast<uint8_t*>(image.data), static_cast<int>(image.size[0]), static_cast<int>(image.size[1]), nsmooth);
 }
 
+// pocketfft_1D(image, sigma) (Source.cpp:280-392) and pocketfft_2D(image, sigma) (Source.cpp:143-277): the two
+// pocketfft paths multiply all N/2+1 bins with the kernel's own spectrum (no Nyquist-slot quirk) and, inside the
+// cropped image, both equal the linear convolution of the reflect-101 extended image -- the engine's
+// nyquist_quirk = 0 mode (tests/ check it against a scipy.fft = pocketfft restatement of both).
+template <class Mat, class = decltype(std::declval<Mat&>().size[0])> void pocketfft_1D(Mat& image, double nsmooth)
+{
+    blur_opts o;
+    blur_opts_default(&o);
+    o.nyquist_quirk = 0;
+    pffft_(reinterpret_cast<uint8_t*>(image.data), static_cast<int>(image.size[0]), static_cast<int>(image.size[1]), nsmooth, nullptr, &o);
+}
+template <class Mat, class = decltype(std::declval<Mat&>().size[0])> void pocketfft_2D(Mat& image, double nsmooth)
+{
+    pocketfft_1D(image, nsmooth);
+}
+
 }  // namespace compat
 }  // namespace blur_amd
 
@@ -195,5 +212,7 @@ using blur_amd::compat::interleave_BGR;
 using blur_amd::compat::isValidSize;
 using blur_amd::compat::nearestTransformSize;
 using blur_amd::compat::pffft_;
+using blur_amd::compat::pocketfft_1D;
+using blur_amd::compat::pocketfft_2D;
 using blur_amd::compat::Reflect_101;
 #endif

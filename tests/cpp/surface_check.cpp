@@ -89,6 +89,15 @@ int main(int argc, char** argv)
             std::ofstream(argv[6], std::ios::binary).write((const char*)img.data(), img.size());
             return 0;
         }
+        if ((mode == "pocket1d" || mode == "pocket2d") && argc == 7) {
+            std::vector<uint8_t> img = slurp(argv[2]);
+            FakeMat m{ img.data(), { std::atoi(argv[3]), std::atoi(argv[4]) } };
+            if (img.size() != (size_t)m.size[0] * m.size[1] * 3) { std::printf("bad input size\n"); return 2; }
+            if (mode == "pocket1d") pocketfft_1D(m, std::atof(argv[5]));
+            else pocketfft_2D(m, std::atof(argv[5]));
+            std::ofstream(argv[6], std::ios::binary).write((const char*)img.data(), img.size());
+            return 0;
+        }
         if (mode == "box" && argc == 9) {
             std::vector<uint8_t> img = slurp(argv[2]);
             fastboxblur(img.data(), std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]), std::atoi(argv[7]));

@@ -152,6 +152,22 @@ def test_host_entry_point_matches_device(ctx):
     assert np.array_equal(dev, host)
 
 
+@pytest.mark.parametrize("rows,cols,sigma", [(270, 480, 20.0), (101, 77, 4.5), (540, 960, 9.0)])
+@pytest.mark.parametrize("path", ["pocketfft_1D", "pocketfft_2D"])
+def test_pocketfft_paths(ctx, rows, cols, sigma, path):
+    """the engine's pocketfft_1D / pocketfft_2D against scipy.fft (pocketfft) restatements of
+    Source.cpp:280-392 and :143-277 -- float64 planes for the tie rule, and the float32 run (what the reference
+    computes) must agree with the engine at least as well as it agrees with float64."""
+    from oracle import pocketfft_paths as P
+    fn = {"pocketfft_1D": P.pocketfft_1d_u8c3, "pocketfft_2D": P.pocketfft_2d_u8c3}[path]
+    img = _rand_img(rows, cols, rows + cols)
+    want, planes = fn(img, sigma, np.float64, want_planes=True)
+    got = getattr(ctx, path)(_torch().from_numpy(img).cuda(), sigma).cpu().numpy()
+    assert_u8_parity(got, want, planes)
+    ref32 = fn(img, sigma, np.float32)
+    assert (got != want).sum() <= max(8, 2 * (ref32 != want).sum())
+
+
 def test_pitched_host_image_like_a_cv_mat_roi(ctx):
     """rows that are farther apart than cols*3 bytes (a region of interest of a larger image)"""
     big = _rand_img(140, 200, 6)
@@ -403,6 +419,10 @@ def test_cpp_surface_on_gpu(ctx, tmp_path):
     got = np.frombuffer((tmp_path / "out.raw").read_bytes(), np.uint8).reshape(img.shape)
     want = ctx.pffft_(torch.from_numpy(img).cuda(), 6.0).cpu().numpy()
     assert np.array_equal(got, want)
+    want = ctx.pocketfft_1D(torch.from_numpy(img).cuda(), 6.0).cpu().numpy()
+    for mode in ("pocket1d", "pocket2d"):
+        subprocess.check_call([exe, mode, str(tmp_path / "in.raw"), "96", "140", "6.0", str(tmp_path / "out.raw")])
+        assert np.array_equal(np.frombuffer((tmp_path / "out.raw").read_bytes(), np.uint8).reshape(img.shape), want)
     subprocess.check_call([exe, "box", str(tmp_path / "in.raw"), "140", "96", "3", "9", "2", str(tmp_path / "box.raw")])
     got = np.frombuffer((tmp_path / "box.raw").read_bytes(), np.uint8).reshape(img.shape)
     from oracle import oracle as O

@@ -176,6 +176,25 @@ def test_f64_oracle_against_independent_numpy_pipeline(rows, cols, sigma, quirk)
     assert np.abs(planes.astype(np.float64) - ref).max() < 2e-5
 
 
+@pytest.mark.parametrize("rows,cols,sigma", [(90, 140, 6.0), (270, 480, 20.0), (101, 77, 4.5), (64, 64, 3.0)])
+@pytest.mark.parametrize("path", ["pocketfft_1d_u8c3", "pocketfft_2d_u8c3"])
+def test_oracle_without_quirk_equals_the_pocketfft_paths(rows, cols, sigma, path):
+    """pocketfft_1D (Source.cpp:280-392) and pocketfft_2D (Source.cpp:143-277) restated on scipy.fft -- the pocketfft
+    library the reference calls -- against this repo's own FFT restatement with the Nyquist quirk off: the three paths
+    are one linear convolution.  float64 transforms agree to the float32 rounding of the returned planes; pocketfft in
+    float32 (what the reference runs) sits within the engine's tolerance of both."""
+    from oracle import pocketfft_paths as P
+    img = np.random.default_rng(rows * 7 + cols).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, False, want_planes=True)
+    u64, p64 = getattr(P, path)(img, sigma, np.float64, want_planes=True)
+    assert np.abs(p64.astype(np.float64) - planes).max() <= 3.1e-5          # two float32 roundings of values < 256
+    u32, p32 = getattr(P, path)(img, sigma, np.float32, want_planes=True)
+    assert np.abs(p32.astype(np.float64) - planes).max() <= 1.5e-4
+    for u in (u64, u32):
+        d = u.astype(int) - want.astype(int)
+        assert np.abs(d).max() <= 1 and (d != 0).mean() < 2e-3
+
+
 def test_f32_port_agrees_with_f64_oracle():
     img = np.random.default_rng(4).integers(0, 256, (270, 480, 3), dtype=np.uint8)
     a = O.pffft_blur_u8c3_f32(img, 20.0)
