@@ -45,6 +45,7 @@ SYMBOLS = {
     "blur_gaussian_u8c3_batch_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
     "blur_gaussian_f32c1_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
     "blur_gaussian_u8c3_host": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
+    "blur_gaussian_u8c3_host_batch": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
     "blur_gaussian_u8c3_host_pitched": (C.c_int, [_P, _P, C.c_size_t, _P, C.c_size_t, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
     "blur_gaussian_f32c1_host": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
     "blur_separable_u8c3_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P, C.c_int, C.c_int, C.POINTER(BlurOpts)]),
@@ -59,6 +60,8 @@ SYMBOLS = {
     "blur_fastboxblur_u8_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "blur_malloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
     "blur_free": (C.c_int, [_P, _P]),
+    "blur_host_alloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
+    "blur_host_free": (C.c_int, [_P, _P]),
     "blur_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "blur_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
 }

@@ -178,6 +178,31 @@ class BlurContext:
         self._check(self._lib.blur_gaussian_u8c3_batch_dev(self._h, t.data_ptr(), dst.data_ptr(), n, rows, cols, float(sigma), C.byref(o)))
         return dst
 
+    def pinned_empty(self, shape, dtype=np.uint8):
+        """numpy array in page-locked host memory (blur_host_alloc); freed when the array and its views are gone"""
+        import weakref
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        p = C.c_void_p()
+        self._check(self._lib.blur_host_alloc(self._h, C.byref(p), n))
+        raw = (C.c_uint8 * max(n, 1)).from_address(p.value)
+        lib, h, addr = self._lib, self._h, p.value
+        weakref.finalize(raw, lambda: lib.blur_host_free(h, addr))
+        return np.frombuffer(raw, np.uint8, n).view(dtype).reshape(shape)
+
+    def pffft_host_batch(self, frames, sigma, out=None, nyquist_quirk=True):
+        """frames: numpy uint8 [n, rows, cols, 3] in host memory (pinned_empty() for full PCIe overlap);
+        copies in, kernels and copies out are pipelined over three device slots.  Returns `out` (default: a new array)."""
+        a = frames
+        if not (isinstance(a, np.ndarray) and a.dtype == np.uint8 and a.ndim == 4 and a.shape[3] == 3 and a.flags["C_CONTIGUOUS"]):
+            raise ValueError("expected a contiguous uint8 array [n, rows, cols, 3]")
+        res = np.empty_like(a) if out is None else out
+        if res.shape != a.shape or res.dtype != np.uint8 or not res.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must match the input")
+        o = self._opts(nyquist_quirk)
+        self._check(self._lib.blur_gaussian_u8c3_host_batch(self._h, a.ctypes.data, res.ctypes.data, a.shape[0], a.shape[1], a.shape[2],
+                                                            float(sigma), C.byref(o)))
+        return res
+
     def pocketfft_1D(self, image, sigma, out=None, **kw):
         """pocketfft_1D(image, sigma) (Source.cpp:280-392): the same 1D tiles as pffft_() with N/2+1 bins and the
         true Nyquist multiplier (:362,:378) -- this engine's `nyquist_quirk = 0` mode."""

@@ -345,8 +345,20 @@ struct DevicePlan {
     int key = 0;
 };
 
+// staging for blur_gaussian_u8c3_host_batch: frame i+1 travels to the device and frame i-1 back to the host
+// while frame i is in the kernels (three slots, two copy streams beside the context's kernel stream)
+struct HostPipe {
+    static constexpr int S = 3;
+    hipStream_t h2d = nullptr, d2h = nullptr;
+    uint8_t* buf[S] = { nullptr, nullptr, nullptr };
+    size_t bytes = 0;
+    hipEvent_t in_done[S] = {}, comp_done[S] = {}, out_done[S] = {};
+    bool ready = false;
+};
+
 struct blur_ctx {
     int device = 0;
+    HostPipe pipe;
     hipStream_t stream = nullptr;
     std::string err;
     std::map<int, std::unique_ptr<DevicePlan>> plans;   // key: 4*n + role (0 generic, 1 specialised row, 2 specialised column)
@@ -757,6 +769,18 @@ int blur_ctx_destroy(blur_ctx* ctx)
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->work2) (void)hipFree(ctx->work2);
     if (ctx->box_tmp) (void)hipFree(ctx->box_tmp);
+    if (ctx->pipe.ready) {
+        (void)hipStreamSynchronize(ctx->pipe.h2d);
+        (void)hipStreamSynchronize(ctx->pipe.d2h);
+        for (int k = 0; k < HostPipe::S; ++k) {
+            if (ctx->pipe.buf[k]) (void)hipFree(ctx->pipe.buf[k]);
+            (void)hipEventDestroy(ctx->pipe.in_done[k]);
+            (void)hipEventDestroy(ctx->pipe.comp_done[k]);
+            (void)hipEventDestroy(ctx->pipe.out_done[k]);
+        }
+        (void)hipStreamDestroy(ctx->pipe.h2d);
+        (void)hipStreamDestroy(ctx->pipe.d2h);
+    }
     for (auto& t : ctx->ev_busy) { (void)hipEventDestroy(std::get<0>(t)); (void)hipEventDestroy(std::get<1>(t)); }
     for (auto& t : ctx->ev_free) { (void)hipEventDestroy(t.first); (void)hipEventDestroy(t.second); }
     delete ctx;
@@ -925,6 +949,60 @@ int blur_gaussian_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int
     return rc;
 }
 
+int blur_gaussian_u8c3_host_batch(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int nframes, int rows, int cols, double sigma,
+                                  const blur_opts* opts)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!src || !dst || nframes < 0 || rows <= 0 || cols <= 0) return fail(ctx, BLUR_ERR_INVALID, "null image, negative count or non-positive size");
+    if (nframes == 0) return BLUR_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t fb = static_cast<size_t>(rows) * cols * 3;
+    HostPipe& p = ctx->pipe;
+    constexpr int S = HostPipe::S;
+    if (!p.ready) {
+        // non-blocking: the context's stream may be the null stream, which would otherwise serialise with these
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&p.h2d, hipStreamNonBlocking));
+        HIP_TRY(ctx, hipStreamCreateWithFlags(&p.d2h, hipStreamNonBlocking));
+        for (int k = 0; k < S; ++k) {
+            HIP_TRY(ctx, hipEventCreateWithFlags(&p.in_done[k], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&p.comp_done[k], hipEventDisableTiming));
+            HIP_TRY(ctx, hipEventCreateWithFlags(&p.out_done[k], hipEventDisableTiming));
+        }
+        p.ready = true;
+    }
+    if (p.bytes < fb) {
+        for (int k = 0; k < S; ++k) {
+            if (p.buf[k]) { HIP_TRY(ctx, hipFree(p.buf[k])); p.buf[k] = nullptr; }
+        }
+        p.bytes = 0;
+        for (int k = 0; k < S; ++k) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&p.buf[k]), fb));
+        p.bytes = fb;
+    }
+    int rc = BLUR_OK;
+    hipError_t e = hipSuccess;
+    auto step = [&](hipError_t r) { if (e == hipSuccess) e = r; return e == hipSuccess; };
+    for (int i = 0; i < nframes && e == hipSuccess && rc == BLUR_OK; ++i) {
+        const int k = i % S;
+        if (i >= S && !step(hipStreamWaitEvent(p.h2d, p.out_done[k], 0))) break;   // the slot's previous frame has left
+        if (!step(hipMemcpyAsync(p.buf[k], src + static_cast<size_t>(i) * fb, fb, hipMemcpyHostToDevice, p.h2d))) break;
+        if (!step(hipEventRecord(p.in_done[k], p.h2d))) break;
+        if (!step(hipStreamWaitEvent(ctx->stream, p.in_done[k], 0))) break;
+        rc = blur_gaussian_u8c3_dev(ctx, p.buf[k], p.buf[k], rows, cols, sigma, opts);
+        if (rc != BLUR_OK) break;
+        if (!step(hipEventRecord(p.comp_done[k], ctx->stream))) break;
+        if (!step(hipStreamWaitEvent(p.d2h, p.comp_done[k], 0))) break;
+        if (!step(hipMemcpyAsync(dst + static_cast<size_t>(i) * fb, p.buf[k], fb, hipMemcpyDeviceToHost, p.d2h))) break;
+        if (!step(hipEventRecord(p.out_done[k], p.d2h))) break;
+    }
+    // drain everything that was queued, whatever happened above
+    const std::string first_err = ctx->err;
+    const hipError_t s0 = hipStreamSynchronize(p.h2d), s1 = hipStreamSynchronize(ctx->stream), s2 = hipStreamSynchronize(p.d2h);
+    if (rc != BLUR_OK) { ctx->err = first_err; return rc; }
+    for (hipError_t r : { s0, s1, s2 }) step(r);
+    if (e != hipSuccess) { ctx->err = std::string("host batch blur: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
+    return BLUR_OK;
+}
+
 int blur_gaussian_u8c3_host_pitched(blur_ctx* ctx, const uint8_t* src, size_t src_pitch, uint8_t* dst, size_t dst_pitch,
                                     int rows, int cols, double sigma, const blur_opts* opts)
 {
@@ -1091,6 +1169,21 @@ int blur_malloc(blur_ctx* ctx, void** d_ptr, size_t bytes)
     if (!ctx || !d_ptr) return BLUR_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMalloc(d_ptr, bytes ? bytes : 1));
+    return BLUR_OK;
+}
+
+int blur_host_alloc(blur_ctx* ctx, void** h_ptr, size_t bytes)
+{
+    if (!ctx || !h_ptr) return BLUR_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipHostMalloc(h_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return BLUR_OK;
+}
+
+int blur_host_free(blur_ctx* ctx, void* h_ptr)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    HIP_TRY(ctx, hipHostFree(h_ptr));
     return BLUR_OK;
 }
 

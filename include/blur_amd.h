@@ -127,6 +127,13 @@ int blur_gaussian_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst,
                             int rows, int cols, double sigma, const blur_opts* opts);
 int blur_gaussian_f32c1_host(blur_ctx* ctx, const float* src, float* dst,
                              int rows, int cols, double sigma, const blur_opts* opts);
+/* nframes frames back to back in host memory (a video-style caller: the loop around pffft_() in Test(),
+   Source.cpp:627-635, with the frames of a clip instead of sigmas).  Frame i+1 is copied to the device and frame i-1
+   back while frame i is in the kernels; with pinned host memory (blur_host_alloc) the copies run at PCIe rate in both
+   directions at once, with pageable memory the call is still correct but the copies serialise.  src == dst allowed.
+   Synchronous. */
+int blur_gaussian_u8c3_host_batch(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int nframes,
+                                  int rows, int cols, double sigma, const blur_opts* opts);
 /* the same for images whose rows are src_pitch / dst_pitch BYTES apart (cv::Mat::step of a ROI or
    of a padded Mat; pffft_() itself assumes image.data is continuous, Source.cpp:459-461) */
 int blur_gaussian_u8c3_host_pitched(blur_ctx* ctx, const uint8_t* src, size_t src_pitch, uint8_t* dst, size_t dst_pitch,
@@ -176,6 +183,10 @@ int blur_malloc(blur_ctx* ctx, void** d_ptr, size_t bytes);
 int blur_free(blur_ctx* ctx, void* d_ptr);
 int blur_memcpy_h2d(blur_ctx* ctx, void* d_dst, const void* src, size_t bytes);   /* synchronous */
 int blur_memcpy_d2h(blur_ctx* ctx, void* dst, const void* d_src, size_t bytes);   /* synchronous */
+/* page-locked host memory (the role PFAlloc plays for pffft's aligned buffers, Utils.hpp:57-138: memory the
+   transport wants): host images that live here are copied by DMA without a staging pass */
+int blur_host_alloc(blur_ctx* ctx, void** h_ptr, size_t bytes);
+int blur_host_free(blur_ctx* ctx, void* h_ptr);
 
 #ifdef __cplusplus
 }

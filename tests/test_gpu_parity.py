@@ -168,6 +168,23 @@ def test_pocketfft_paths(ctx, rows, cols, sigma, path):
     assert (got != want).sum() <= max(8, 2 * (ref32 != want).sum())
 
 
+@pytest.mark.parametrize("pinned", [False, True])
+def test_host_batch_pipeline_equals_frame_by_frame(ctx, pinned):
+    """7 host frames through the three-slot copy/compute pipeline (more frames than slots, so slots are reused)"""
+    n, rows, cols = 7, 120, 200
+    src = np.random.default_rng(77).integers(0, 256, (n, rows, cols, 3), dtype=np.uint8)
+    if pinned:
+        buf = ctx.pinned_empty(src.shape)
+        buf[...] = src
+        out = ctx.pffft_host_batch(buf, 5.0, out=ctx.pinned_empty(src.shape))
+        inplace = ctx.pffft_host_batch(buf, 5.0, out=buf)
+        assert inplace is buf and np.array_equal(buf, out)
+    else:
+        out = ctx.pffft_host_batch(src, 5.0)
+    for i in range(n):
+        assert np.array_equal(out[i], ctx.pffft_(src[i], 5.0)), i
+
+
 def test_pitched_host_image_like_a_cv_mat_roi(ctx):
     """rows that are farther apart than cols*3 bytes (a region of interest of a larger image)"""
     big = _rand_img(140, 200, 6)
