@@ -57,6 +57,22 @@
 #ifndef FK_GATHER_UNROLL
 #define FK_GATHER_UNROLL 4          // independent strip-gather loads a thread keeps in flight (column kernel)
 #endif
+// ablation builds of the in-LDS passes (timing only, results are wrong): -DFK_ABL_NOLDSW drops the LDS stores of the
+// inner and middle passes (two adds per element keep the arithmetic alive), -DFK_ABL_NOMATH drops the butterflies
+#ifdef FK_ABL_NOLDSW
+#define FK_ST(dst, val) do { const float2 v_ = (val); fk_abl_acc += v_.x + v_.y; } while (0)
+#define FK_ABL_DECL float fk_abl_acc = 0.f
+#define FK_ABL_SINK(ptr) do { if (fk_abl_acc == 1.2345e30f) (ptr)[0] = make_float2(fk_abl_acc, 0.f); } while (0)
+#else
+#define FK_ST(dst, val) (dst) = (val)
+#define FK_ABL_DECL do { } while (0)
+#define FK_ABL_SINK(ptr) do { } while (0)
+#endif
+#ifdef FK_ABL_NOMATH
+#define FK_BFLY(R, INV, v) do { } while (0)
+#else
+#define FK_BFLY(R, INV, v) Bfly<R, INV>::run(v)
+#endif
 #define FK_PRAGMA(x) _Pragma(#x)
 #define FK_UNROLL(n) FK_PRAGMA(unroll n)
 
@@ -145,6 +161,7 @@ __device__ __forceinline__ int fk_reflect_src(int p, int pad, int len)
 template <class PL, int I, int C, int T, bool INV>
 __device__ __forceinline__ void fk_inner_pass(float2* z, int zs, const float2* twl)
 {
+    FK_ABL_DECL;
     constexpr int R = PL::R[I], m = PL::m(I), nb = PL::nb(I), total = nb * C;
     constexpr int off = PL::tw_off(I) - PL::lds_tw_begin();
     constexpr bool hoist = R <= FK_HOIST_MAX_R;
@@ -176,24 +193,25 @@ __device__ __forceinline__ void fk_inner_pass(float2* z, int zs, const float2* t
 #pragma unroll
         for (int bi = 0; bi < B; ++bi) {
             if constexpr (!INV) {
-                Bfly<R, false>::run(v[bi]);
+                FK_BFLY(R, false, v[bi]);
                 if (act[bi]) {
-                    zc[bi][PL::at(base[bi])] = v[bi][0];
+                    FK_ST(zc[bi][PL::at(base[bi])], v[bi][0]);
 #pragma unroll
                     for (int q = 1; q < R; ++q)
-                        zc[bi][PL::at(base[bi] + q * m)] = cmul(v[bi][q], hoist ? w[bi][q] : twl[off + (q - 1) * m + jj[bi]]);
+                        FK_ST(zc[bi][PL::at(base[bi] + q * m)], cmul(v[bi][q], hoist ? w[bi][q] : twl[off + (q - 1) * m + jj[bi]]));
                 }
             } else {
 #pragma unroll
                 for (int q = 1; q < R; ++q) v[bi][q] = cmulc(v[bi][q], hoist ? w[bi][q] : twl[off + (q - 1) * m + jj[bi]]);
-                Bfly<R, true>::run(v[bi]);
+                FK_BFLY(R, true, v[bi]);
                 if (act[bi]) {
 #pragma unroll
-                    for (int k = 0; k < R; ++k) zc[bi][PL::at(base[bi] + k * m)] = v[bi][k];
+                    for (int k = 0; k < R; ++k) FK_ST(zc[bi][PL::at(base[bi] + k * m)], v[bi][k]);
                 }
             }
         }
     }
+    FK_ABL_SINK(z);
 }
 
 template <class PL, int I, int C, int T, bool INV>
@@ -247,10 +265,10 @@ template <class PL, int T, int C> struct MidRegs {
                     float2 v[R];
 #pragma unroll
                     for (int k = 0; k < R; ++k) v[k] = zc[PL::at(b * R + k)];
-                    Bfly<R, false>::run(v);
+                    FK_BFLY(R, false, v);
 #pragma unroll
                     for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mm[it][q]);
-                    Bfly<R, true>::run(v);
+                    FK_BFLY(R, true, v);
 #pragma unroll
                     for (int k = 0; k < R; ++k) zc[PL::at(b * R + k)] = v[k];
                 }
@@ -263,6 +281,7 @@ template <class PL, int T, int C> struct MidRegs {
 template <class PL, int T, int C>
 __device__ __forceinline__ void fk_mid_lds(float2* z, int zs, const float* __restrict__ mpl)
 {
+    FK_ABL_DECL;
     constexpr int R = PL::R[PL::P - 1], nb = PL::nb(PL::P - 1), total = nb * C;
     constexpr int B = (R <= FK_BATCH_MAX_R && total > T) ? FK_INNER_BATCH : 1;
 #pragma unroll 1
@@ -288,16 +307,17 @@ __device__ __forceinline__ void fk_mid_lds(float2* z, int zs, const float* __res
         if constexpr (R <= FK_HOIST_MAX_R) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int bi = 0; bi < B; ++bi) {
-            Bfly<R, false>::run(v[bi]);
+            FK_BFLY(R, false, v[bi]);
 #pragma unroll
             for (int q = 0; q < R; ++q) v[bi][q] = cscale(v[bi][q], mm[bi][q]);
-            Bfly<R, true>::run(v[bi]);
+            FK_BFLY(R, true, v[bi]);
             if (act[bi]) {
 #pragma unroll
-                for (int k = 0; k < R; ++k) zc[bi][PL::at(base[bi] + k)] = v[bi][k];
+                for (int k = 0; k < R; ++k) FK_ST(zc[bi][PL::at(base[bi] + k)], v[bi][k]);
             }
         }
     }
+    FK_ABL_SINK(z);
 }
 
 // ---- wave-local inner section ------------------------------------------------------------------
@@ -317,6 +337,7 @@ __device__ __forceinline__ void fk_wave_sync()
 template <class PL, int I, int C, int T, bool INV>
 __device__ __forceinline__ void fk_inner_pass_wave(float2* z, int zs, const float2* twl)
 {
+    FK_ABL_DECL;
     constexpr int R0 = PL::R[0], m0 = PL::m(0);
     constexpr int R = PL::R[I], m = PL::m(I), nbs = m0 / R;       // butterflies per sub-block
     constexpr int W = T / 64, S = R0 * C;
@@ -340,37 +361,39 @@ __device__ __forceinline__ void fk_inner_pass_wave(float2* z, int zs, const floa
             for (int q = 1; q < R; ++q) w[q] = twl[off + (q - 1) * m + j];
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (!INV) {
-                Bfly<R, false>::run(v);
-                zc[PL::at(base)] = v[0];
+                FK_BFLY(R, false, v);
+                FK_ST(zc[PL::at(base)], v[0]);
 #pragma unroll
-                for (int q = 1; q < R; ++q) zc[PL::at(base + q * m)] = cmul(v[q], w[q]);
+                for (int q = 1; q < R; ++q) FK_ST(zc[PL::at(base + q * m)], cmul(v[q], w[q]));
             } else {
 #pragma unroll
                 for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], w[q]);
-                Bfly<R, true>::run(v);
+                FK_BFLY(R, true, v);
 #pragma unroll
-                for (int k = 0; k < R; ++k) zc[PL::at(base + k * m)] = v[k];
+                for (int k = 0; k < R; ++k) FK_ST(zc[PL::at(base + k * m)], v[k]);
             }
         } else {
             if constexpr (!INV) {
-                Bfly<R, false>::run(v);
-                zc[PL::at(base)] = v[0];
+                FK_BFLY(R, false, v);
+                FK_ST(zc[PL::at(base)], v[0]);
 #pragma unroll
-                for (int q = 1; q < R; ++q) zc[PL::at(base + q * m)] = cmul(v[q], twl[off + (q - 1) * m + j]);
+                for (int q = 1; q < R; ++q) FK_ST(zc[PL::at(base + q * m)], cmul(v[q], twl[off + (q - 1) * m + j]));
             } else {
 #pragma unroll
                 for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], twl[off + (q - 1) * m + j]);
-                Bfly<R, true>::run(v);
+                FK_BFLY(R, true, v);
 #pragma unroll
-                for (int k = 0; k < R; ++k) zc[PL::at(base + k * m)] = v[k];
+                for (int k = 0; k < R; ++k) FK_ST(zc[PL::at(base + k * m)], v[k]);
             }
         }
     }
+    FK_ABL_SINK(z);
 }
 
 template <class PL, int C, int T>
 __device__ __forceinline__ void fk_mid_wave(float2* z, int zs, const float* __restrict__ mpl)
 {
+    FK_ABL_DECL;
     constexpr int R0 = PL::R[0], m0 = PL::m(0);
     constexpr int R = PL::R[PL::P - 1], nbs = m0 / R;
     constexpr int W = T / 64, S = R0 * C;
@@ -390,13 +413,14 @@ __device__ __forceinline__ void fk_mid_wave(float2* z, int zs, const float* __re
 #pragma unroll
         for (int q = 0; q < R; ++q) mm[q] = mpl[base + q];
         if constexpr (R <= FK_HOIST_MAX_R) __builtin_amdgcn_sched_barrier(0);
-        Bfly<R, false>::run(v);
+        FK_BFLY(R, false, v);
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mm[q]);
-        Bfly<R, true>::run(v);
+        FK_BFLY(R, true, v);
 #pragma unroll
-        for (int k = 0; k < R; ++k) zc[PL::at(base + k)] = v[k];
+        for (int k = 0; k < R; ++k) FK_ST(zc[PL::at(base + k)], v[k]);
     }
+    FK_ABL_SINK(z);
 }
 
 template <class PL, int I, int C, int T, bool INV>
