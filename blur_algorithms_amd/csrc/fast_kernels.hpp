@@ -98,13 +98,18 @@ constexpr int kStampTailFloats = 1 << 16;
 #endif
 
 // ---- static plan ---------------------------------------------------------------------
-// PAD_: LDS line padding policy.  0 = none (element i at i); 1 = one spare element per 32
-// (fft_engine.hpp PL::at()): only plans whose inner passes stride by a multiple of 32 elements
-// need it, and it costs three VALU instructions per LDS address.
-template <int N_, int PAD_, int... Rs> struct StaticPlan {
+// FLAGS_ (bits):
+//   1  LDS line padding: one spare element per 32 (element i at i + (i >> 5)) instead of none.  Only plans whose inner
+//      passes stride by a multiple of 32 elements need it, and it costs three VALU instructions per LDS address.
+//   2  register diet: inner passes of radix > 10 read their twiddles where they are used instead of up front
+//   4  column kernel: pass 0's twiddles live in LDS (behind the pixel stage) instead of registers
+//   (2 and 4 together free ~45 VGPRs: what the 2304 column plan needs to run 12 waves per CU with the strip prefetch)
+template <int N_, int FLAGS_, int... Rs> struct StaticPlan {
     static constexpr int N = N_;
-    static constexpr int PAD = PAD_;
-    static __host__ __device__ constexpr int at(int i) { return PAD_ ? i + (i >> 5) : i; }
+    static constexpr int PAD = FLAGS_ & 1;
+    static constexpr int hoist_max = (FLAGS_ & 2) ? (FK_HOIST_MAX_R < 10 ? FK_HOIST_MAX_R : 10) : FK_HOIST_MAX_R;
+    static constexpr bool tw0_lds = (FLAGS_ & 4) != 0;
+    static __host__ __device__ constexpr int at(int i) { return PAD ? i + (i >> 5) : i; }
     static __host__ __device__ constexpr int zs() { return at(N_) + 1; }
     static constexpr int P = sizeof...(Rs);
     static constexpr int R[P] = { Rs... };
@@ -156,7 +161,7 @@ __device__ __forceinline__ int fk_reflect_src(int p, int pad, int len)
 // ---- inner passes on LDS, flattened over (line, butterfly) ----------------------------------
 // FK_INNER_BATCH butterflies of a thread are read together (data and twiddles of all of them
 // before the first use), so that one LDS latency is paid per batch and the second butterfly's
-// reads are in flight while the first is computed.  Radices above FK_HOIST_MAX_R keep batch 1 and
+// reads are in flight while the first is computed.  Radices above PL::hoist_max keep batch 1 and
 // read their twiddles where they are used (register pressure).
 template <class PL, int I, int C, int T, bool INV>
 __device__ __forceinline__ void fk_inner_pass(float2* z, int zs, const float2* twl)
@@ -164,7 +169,7 @@ __device__ __forceinline__ void fk_inner_pass(float2* z, int zs, const float2* t
     FK_ABL_DECL;
     constexpr int R = PL::R[I], m = PL::m(I), nb = PL::nb(I), total = nb * C;
     constexpr int off = PL::tw_off(I) - PL::lds_tw_begin();
-    constexpr bool hoist = R <= FK_HOIST_MAX_R;
+    constexpr bool hoist = R <= PL::hoist_max;
     constexpr int B = (hoist && R <= FK_BATCH_MAX_R && total > T) ? FK_INNER_BATCH : 1;
 #pragma unroll 1
     for (int g0 = threadIdx.x; g0 < total; g0 += T * B) {
@@ -304,7 +309,7 @@ __device__ __forceinline__ void fk_mid_lds(float2* z, int zs, const float* __res
 #pragma unroll
             for (int q = 0; q < R; ++q) mm[bi][q] = mpl[base[bi] + q];
         }
-        if constexpr (R <= FK_HOIST_MAX_R) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (R <= PL::hoist_max) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int bi = 0; bi < B; ++bi) {
             FK_BFLY(R, false, v[bi]);
@@ -355,7 +360,7 @@ __device__ __forceinline__ void fk_inner_pass_wave(float2* z, int zs, const floa
         float2 v[R];
 #pragma unroll
         for (int k = 0; k < R; ++k) v[k] = zc[PL::at(base + k * m)];
-        if constexpr (R <= FK_HOIST_MAX_R) {
+        if constexpr (R <= PL::hoist_max) {
             float2 w[R];
 #pragma unroll
             for (int q = 1; q < R; ++q) w[q] = twl[off + (q - 1) * m + j];
@@ -412,7 +417,7 @@ __device__ __forceinline__ void fk_mid_wave(float2* z, int zs, const float* __re
         for (int k = 0; k < R; ++k) v[k] = zc[PL::at(base + k)];
 #pragma unroll
         for (int q = 0; q < R; ++q) mm[q] = mpl[base + q];
-        if constexpr (R <= FK_HOIST_MAX_R) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (R <= PL::hoist_max) __builtin_amdgcn_sched_barrier(0);
         FK_BFLY(R, false, v);
 #pragma unroll
         for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mm[q]);
@@ -744,8 +749,18 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
     unsigned long long st_acc[kStampSlots] = {};
     unsigned long long st_prev = __builtin_amdgcn_s_memtime();
 #endif
+    // pass 0's twiddles: registers (butterfly j0 of pass 0 is this thread's for every line), or LDS for plans on a register diet
+    float2* const tw0l = reinterpret_cast<float2*>(stage + ((static_cast<size_t>(rows) * G * CH + 15) & ~static_cast<size_t>(15)));
     Pass0Regs<PL, T> p0;
-    p0.load(tw, j0);
+    if constexpr (PL::tw0_lds) {
+        for (int i = threadIdx.x; i < (R0 - 1) * m0; i += T) tw0l[i] = tw[i];
+    } else {
+        p0.load(tw, j0);
+    }
+    auto p0w = [&](int it, int q, int j) -> float2 {
+        if constexpr (PL::tw0_lds) return tw0l[(q - 1) * m0 + j];
+        else return p0.w[it][q];
+    };
     for (int i = threadIdx.x; i < PL::lds_tw_count(); i += T) twl[i] = tw[PL::lds_tw_begin() + i];
     for (int i = threadIdx.x; i < N; i += T) mpl[i] = mperm[i];
 
@@ -890,7 +905,7 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
                             Bfly<R0, false>::run(v);
                             zc[PL::at(j)] = v[0];
 #pragma unroll
-                            for (int q = 1; q < R0; ++q) zc[PL::at(j + q * m0)] = cmul(v[q], p0.w[it][q]);
+                            for (int q = 1; q < R0; ++q) zc[PL::at(j + q * m0)] = cmul(v[q], p0w(it, q, j));
                         }
                     }
                 }
@@ -925,7 +940,7 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
                             float2 v[R0];
                             v[0] = zc[PL::at(j)];
 #pragma unroll
-                            for (int q = 1; q < R0; ++q) v[q] = cmulc(zc[PL::at(j + q * m0)], p0.w[it][q]);
+                            for (int q = 1; q < R0; ++q) v[q] = cmulc(zc[PL::at(j + q * m0)], p0w(it, q, j));
                             Bfly<R0, true>::run(v);
 #pragma unroll
                             for (int k = 0; k < R0; ++k) {
@@ -1002,7 +1017,8 @@ template <class PL> size_t fk_row_lds()
 template <class PL, int C> size_t fk_col_lds(int rows)
 {
     return (static_cast<size_t>(C) * PL::zs() + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) +
-           static_cast<size_t>(PL::N) * sizeof(float) + static_cast<size_t>(rows) * 2 * C * 3 + 16;
+           static_cast<size_t>(PL::N) * sizeof(float) + static_cast<size_t>(rows) * 2 * C * 3 + 16 +
+           (PL::tw0_lds ? static_cast<size_t>(PL::R[0] - 1) * PL::m(0) * sizeof(float2) + 16 : 0);
 }
 
 // grid for `units` equal work items on `slots` resident workgroups: as many rounds as needed, all equally full
