@@ -103,12 +103,16 @@ constexpr int kStampTailFloats = 1 << 16;
 //      passes stride by a multiple of 32 elements need it, and it costs three VALU instructions per LDS address.
 //   2  register diet: inner passes of radix > 10 read their twiddles where they are used instead of up front
 //   4  column kernel: pass 0's twiddles live in LDS (behind the pixel stage) instead of registers
-//   (2 and 4 together free ~45 VGPRs: what the 2304 column plan needs to run 12 waves per CU with the strip prefetch)
+//  16  row kernel: compile for 4 waves per SIMD (<= 128 VGPRs) instead of FK_ROW_WAVES_PER_SIMD
+//   8  column kernel: compile for 3 waves per SIMD (<= 168 VGPRs) although one workgroup alone would not need it, so
+//      that TWO workgroups fit a CU when their LDS does (short lines)
 template <int N_, int FLAGS_, int... Rs> struct StaticPlan {
     static constexpr int N = N_;
     static constexpr int PAD = FLAGS_ & 1;
     static constexpr int hoist_max = (FLAGS_ & 2) ? (FK_HOIST_MAX_R < 10 ? FK_HOIST_MAX_R : 10) : FK_HOIST_MAX_R;
     static constexpr bool tw0_lds = (FLAGS_ & 4) != 0;
+    static constexpr int col_min_waves = (FLAGS_ & 8) ? 3 : 1;
+    static constexpr int row_waves = (FLAGS_ & 16) ? 4 : FK_ROW_WAVES_PER_SIMD;
     static __host__ __device__ constexpr int at(int i) { return PAD ? i + (i >> 5) : i; }
     static __host__ __device__ constexpr int zs() { return at(N_) + 1; }
     static constexpr int P = sizeof...(Rs);
@@ -142,6 +146,13 @@ struct FastEntry {
                          const float2* tw, const float* mperm, int C);
     size_t (*col_lds_bytes)(int rows, int C);
 };
+
+// LDS of the row kernel: the line, the inner twiddles, the multipliers; multiple of 16
+template <class PL> __host__ __device__ constexpr size_t fk_row_lds_tables()
+{
+    return (((static_cast<size_t>(PL::zs()) + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) +
+             ((FK_ROW_MID_GLOBAL || FK_ROW_MID_REGS) ? 0 : static_cast<size_t>(PL::N) * sizeof(float))) + 15) & ~static_cast<size_t>(15);
+}
 
 __device__ __forceinline__ int fk_xcd_contiguous(int b, int nwg)
 {
@@ -471,7 +482,7 @@ template <class PL, int T> struct Pass0Regs {
 // row pass
 // ======================================================================================
 template <class PL, int T, int CH, int tile_shift>
-__global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ planes,
+__global__ __launch_bounds__(T, PL::row_waves) void fast_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ planes,
                                                      int rows, int cols, int pad, int npairs, int nunits,
                                                      const float2* __restrict__ tw, const float* __restrict__ mperm)
 {
@@ -720,7 +731,7 @@ __global__ __launch_bounds__(T, FK_ROW_WAVES_PER_SIMD) void fast_rowpass_u8(cons
 // column pass
 // ======================================================================================
 template <class PL, int T, int C, int CH, bool tiled, bool WL>
-__global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ planes, uint8_t* __restrict__ dst,
+__global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const float* __restrict__ planes, uint8_t* __restrict__ dst,
                                                      int rows, int cols, int pad, int nstrips, int nunits,
                                                      const float2* __restrict__ tw, const float* __restrict__ mperm)
 {
@@ -1010,8 +1021,7 @@ __global__ __launch_bounds__(T) void fast_colpass_u8(const float* __restrict__ p
 template <class PL> size_t fk_row_lds()
 {
     if (FK_ROW_LDS_EXTRA) return FK_ROW_LDS_EXTRA;
-    return (static_cast<size_t>(PL::zs()) + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) +
-           ((FK_ROW_MID_GLOBAL || FK_ROW_MID_REGS) ? 0 : static_cast<size_t>(PL::N) * sizeof(float));
+    return fk_row_lds_tables<PL>();
 }
 
 template <class PL, int C> size_t fk_col_lds(int rows)
@@ -1033,17 +1043,17 @@ constexpr int kNumCUs = 256;
 template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uint8_t* src, float* planes, int rows, int cols, int pad, int nframes, int tile_w,
                                                const float2* tw, const float* mperm)
 {
-    const size_t lds = fk_row_lds<PL>();
     if (tile_w != 0 && tile_w != 8) return hipErrorInvalidValue;
+    const size_t lds = fk_row_lds<PL>();
     auto kern = tile_w ? fast_rowpass_u8<PL, T, 3, 3> : fast_rowpass_u8<PL, T, 3, 0>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
     }
     const int npairs = (rows + 1) / 2, nunits = npairs * nframes;
-    // resident workgroups per CU: LDS, and FK_ROW_WAVES_PER_SIMD waves on each of the 4 SIMDs
+    // resident workgroups per CU: LDS, and PL::row_waves waves on each of the 4 SIMDs
     int per_cu = static_cast<int>((160 * 1024) / lds);
-    const int by_waves = FK_ROW_WAVES_PER_SIMD * 4 / ((T + 63) / 64);
+    const int by_waves = PL::row_waves * 4 / ((T + 63) / 64);
     if (per_cu > by_waves) per_cu = by_waves;
     if (per_cu < 1) per_cu = 1;
     const int grid = fk_balanced_grid(nunits, kNumCUs * per_cu);
@@ -1062,9 +1072,12 @@ template <class PL, int T, int C, bool WL> hipError_t fk_launch_col_u8_c(hipStre
         if (e != hipSuccess) return e;
     }
     const int nstrips = (cols + 2 * C - 1) / (2 * C), nunits = nstrips * nframes;
-    int per_cu = static_cast<int>((160 * 1024) / lds);
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu * ((T + 63) / 64) > 32) per_cu = 32 / ((T + 63) / 64);
+    // resident workgroups per CU as the runtime sees them (LDS of this image height and the kernel's registers)
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T, lds) != hipSuccess || per_cu < 1) {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
     const int grid = fk_balanced_grid(nunits, kNumCUs * per_cu);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, planes, dst, rows, cols, pad, nstrips, nunits, tw, mperm);
     return hipGetLastError();

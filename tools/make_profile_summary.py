@@ -16,14 +16,19 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "profiles")
 os.makedirs(out, exist_ok=True)
 
-for f in glob.glob(os.path.join(src, "stats", "**", "*_kernel_stats.csv"), recursive=True):
+def newest(pattern):
+    """gpurun merges every call's files into the same directory: only the latest run counts"""
+    files = glob.glob(pattern, recursive=True)
+    return [max(files, key=os.path.getmtime)] if files else []
+
+for f in newest(os.path.join(src, "stats", "**", "*_kernel_stats.csv")):
     shutil.copy(f, os.path.join(out, "%s_kernel_stats.csv" % tag))
 for f in glob.glob(os.path.join(src, "bench_under_rocprof.log")):
     shutil.copy(f, os.path.join(out, "%s_bench_under_rocprof.log" % tag))
 
 def mean_counters(sub):
     acc = collections.defaultdict(lambda: collections.defaultdict(list))
-    for f in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+    for f in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
             name = "fast_rowpass_u8" if "rowpass" in k else "fast_colpass_u8" if "colpass" in k else None
