@@ -63,18 +63,21 @@ def baseline_metric():
         return "megapixels/sec Gaussian blur (\u03c3=20, 4K RGB) at 1/2/4/8 GPUs; % HBM roofline"
 
 
-def pmc_traffic(kernel, frames_per_launch):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate
-    FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied there), or None"""
+def pmc_traffic(role, frames_per_launch):
+    """(kernel name, HBM bytes per launch) of the row / column kernel from the committed rocprofv3 PMC summary
+    (separate FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 corrections applied there); the
+    bytes are None when the summary is missing or was taken with another batching"""
+    default = {"row": "fast_rowpass_u8", "col": "fast_colpass_u8"}[role]
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         t = json.load(open(path))
-        e = t[kernel]
+        name = [k for k in t if role + "pass" in k][0]
+        e = t[name]
         if abs(e["frames_per_launch"] - frames_per_launch) > 1e-9:
-            return None
-        return e["hbm_bytes_per_launch"]
+            return name, None
+        return name, e["hbm_bytes_per_launch"]
     except Exception:
-        return None
+        return default, None
 
 
 def main():
@@ -190,13 +193,14 @@ def main():
             row_ms = tm["row_ms"] / tm["row_launches"]
             col_ms = tm["col_ms"] / tm["col_launches"]
             fpl = tm["row_frames"] / tm["row_launches"]            # frames one launch covers
-            name, dur = ("fast_colpass_u8", col_ms) if col_ms >= row_ms else ("fast_rowpass_u8", row_ms)
+            role, dur = ("col", col_ms) if col_ms >= row_ms else ("row", row_ms)
+            name, traffic = pmc_traffic(role, fpl)
             alg = ALG_BYTES_PER_PX_KERNEL * px * fpl
             achieved = alg / (dur * 1e-3) / 1e9
             rec["roofline"] = {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name, fpl),
-                "avg_launch_ms": {"fast_rowpass_u8": round(row_ms, 4), "fast_colpass_u8": round(col_ms, 4)},
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "avg_launch_ms": {pmc_traffic("row", fpl)[0]: round(row_ms, 4), pmc_traffic("col", fpl)[0]: round(col_ms, 4)},
                 "frames_per_launch": fpl,
                 "alg_bytes_per_launch": alg,
             }

@@ -104,6 +104,8 @@ constexpr int kStampTailFloats = 1 << 16;
 //   2  register diet: inner passes of radix > 10 read their twiddles where they are used instead of up front
 //   4  column kernel: pass 0's twiddles live in LDS (behind the pixel stage) instead of registers
 //  16  row kernel: compile for 4 waves per SIMD (<= 128 VGPRs) instead of FK_ROW_WAVES_PER_SIMD
+//  32  row pass by fast_rowpass3_u8: the three channels of a row pair are transformed together by one workgroup per
+//      CU (pass-0 twiddles in LDS), the way the column kernel treats the four lines of a strip
 //   8  column kernel: compile for 3 waves per SIMD (<= 168 VGPRs) although one workgroup alone would not need it, so
 //      that TWO workgroups fit a CU when their LDS does (short lines)
 template <int N_, int FLAGS_, int... Rs> struct StaticPlan {
@@ -113,6 +115,7 @@ template <int N_, int FLAGS_, int... Rs> struct StaticPlan {
     static constexpr bool tw0_lds = (FLAGS_ & 4) != 0;
     static constexpr int col_min_waves = (FLAGS_ & 8) ? 3 : 1;
     static constexpr int row_waves = (FLAGS_ & 16) ? 4 : FK_ROW_WAVES_PER_SIMD;
+    static constexpr bool row_channels_together = (FLAGS_ & 32) != 0;
     static __host__ __device__ constexpr int at(int i) { return PAD ? i + (i >> 5) : i; }
     static __host__ __device__ constexpr int zs() { return at(N_) + 1; }
     static constexpr int P = sizeof...(Rs);
@@ -728,6 +731,165 @@ __global__ __launch_bounds__(T, PL::row_waves) void fast_rowpass_u8(const uint8_
 }
 
 // ======================================================================================
+// row pass, channels together (plan flag 32)
+// ======================================================================================
+// One workgroup per CU transforms the CH complex lines of a row pair (one per channel) at once, flattened over
+// (channel, butterfly) in every pass -- the column kernel's recipe: many waves in ONE workgroup, every pass close to
+// one full round of butterflies, pass 0's twiddles in LDS so that no pass pins registers across the others.
+// LDS: CH lines | inner twiddles | multipliers | pass-0 twiddles.
+template <class PL, int CH> __host__ __device__ constexpr size_t fk_row3_lds()
+{
+    return (static_cast<size_t>(CH) * PL::zs() + ((PL::lds_tw_count() + 1) & ~1) + static_cast<size_t>(PL::R[0] - 1) * PL::m(0)) * sizeof(float2) +
+           static_cast<size_t>(PL::N) * sizeof(float);
+}
+
+template <class PL, int T, int CH, int tile_shift, bool STAGED>
+__global__ __launch_bounds__(T) void fast_rowpass3_u8(const uint8_t* __restrict__ src, float* __restrict__ planes,
+                                                      int rows, int cols, int pad, int npairs, int nunits,
+                                                      const float2* __restrict__ tw, const float* __restrict__ mperm)
+{
+    static_assert(PL::valid(), "radices do not multiply to N");
+    constexpr int N = PL::N, P = PL::P;
+    constexpr int R0 = PL::R[0], m0 = PL::m(0);
+    constexpr int zs = PL::zs();
+    constexpr int total0 = CH * m0, IT0 = (total0 + T - 1) / T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* z = reinterpret_cast<float2*>(smem);
+    float2* twl = z + CH * zs;
+    float2* tw0l = twl + ((PL::lds_tw_count() + 1) & ~1);
+    float* mpl = reinterpret_cast<float*>(tw0l + (R0 - 1) * m0);
+    constexpr int tile_w = tile_shift ? 1 << tile_shift : 0;
+    const size_t plane_elems = tile_shift ? static_cast<size_t>((cols + tile_w - 1) >> tile_shift) * npairs * (2 * tile_w)
+                                          : static_cast<size_t>(rows) * cols;
+    for (int i = threadIdx.x; i < PL::lds_tw_count(); i += T) twl[i] = tw[PL::lds_tw_begin() + i];
+    for (int i = threadIdx.x; i < (R0 - 1) * m0; i += T) tw0l[i] = tw[i];
+    for (int i = threadIdx.x; i < N; i += T) mpl[i] = mperm[i];
+
+    // STAGED (rows 16-byte aligned, checked by the launcher): the two u8 rows of a unit arrive by 16-byte loads
+    // that were issued into registers while the previous unit was being transformed, are parked in the (then free)
+    // line buffer, and every thread picks its 2*R0 bytes from there before the first butterfly overwrites them.
+    const int rowbytes = cols * CH;
+    uint8_t* const stage = reinterpret_cast<uint8_t*>(z);
+    constexpr int KP = STAGED ? (2 * ((N * CH + 15) / 16) + T - 1) / T : 1;
+    static_assert(!STAGED || 2 * static_cast<size_t>(N) * CH <= static_cast<size_t>(CH) * zs * sizeof(float2), "the stage fits the line buffer");
+    typedef unsigned int fk_u32x4 __attribute__((ext_vector_type(4)));   // a plain vector value: stays in registers
+    fk_u32x4 pfr[KP];
+    auto issue_rows = [&](int uu) {
+        const int ff = uu / npairs, pp = uu - ff * npairs;
+        const uint8_t* a = src + (static_cast<size_t>(ff) * rows + 2 * pp) * rowbytes;
+        const int nchunk = rowbytes >> 4;
+        const int second = (2 * pp + 1 < rows) ? rowbytes : 0;      // a missing second row reads the first again (masked later)
+#pragma unroll
+        for (int k = 0; k < KP; ++k) {
+            int idx = threadIdx.x + T * k;
+            idx = idx < 2 * nchunk ? idx : 2 * nchunk - 1;
+            const int rb = idx >= nchunk ? 1 : 0;
+            pfr[k] = *reinterpret_cast<const fk_u32x4*>(a + (rb ? second : 0) + 16 * (idx - rb * nchunk));
+        }
+    };
+    bool rows_ready = false;
+
+    const int u_begin = static_cast<int>(static_cast<long long>(blockIdx.x) * nunits / gridDim.x);
+    const int u_end = static_cast<int>(static_cast<long long>(blockIdx.x + 1) * nunits / gridDim.x);
+    for (int u = u_begin; u < u_end; ++u) {
+        const int f = u / npairs, pair = u - f * npairs;
+        const int r0 = 2 * pair;
+        const bool two = r0 + 1 < rows;
+        const uint8_t* row_a = src + (static_cast<size_t>(f) * rows + r0) * cols * CH;
+        const uint8_t* row_b = row_a + (two ? static_cast<size_t>(cols) * CH : 0);
+        float* out_u = planes + static_cast<size_t>(f) * plane_elems * CH +
+                       (tile_shift ? static_cast<size_t>(pair) * (2 * tile_w) : static_cast<size_t>(r0) * cols);
+        __syncthreads();   // the previous unit's readers are done with z (and the tables are visible)
+        if constexpr (STAGED) {
+            if (!rows_ready) issue_rows(u);
+            const int nchunk = rowbytes >> 4;
+#pragma unroll
+            for (int k = 0; k < KP; ++k) {
+                const int idx = threadIdx.x + T * k;
+                if (idx < 2 * nchunk) reinterpret_cast<fk_u32x4*>(stage)[idx] = pfr[k];
+            }
+            __syncthreads();
+        }
+        // ---- pass 0: u8 -> butterfly -> twiddle -> LDS, flattened over (channel, butterfly)
+        float2 v0[IT0][R0];
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            int g = threadIdx.x + T * it;
+            g = g < total0 ? g : total0 - 1;
+            const int c = g / m0, j = g - c * m0;
+            uint8_t pa[R0], pb[R0];
+            bool ok[R0];
+#pragma unroll
+            for (int k = 0; k < R0; ++k) {                            // unconditional loads: all in flight together
+                const int x = fk_reflect_src(j + k * m0, pad, cols);
+                ok[k] = x >= 0;
+                const int xi = (x >= 0 ? x : 0) * CH + c;
+                if constexpr (STAGED) {
+                    pa[k] = stage[xi];
+                    pb[k] = stage[rowbytes + xi];
+                } else {
+                    pa[k] = row_a[xi];
+                    pb[k] = row_b[xi];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < R0; ++k)
+                v0[it][k] = make_float2(ok[k] ? static_cast<float>(pa[k]) : 0.f, (ok[k] && two) ? static_cast<float>(pb[k]) : 0.f);
+        }
+        if constexpr (STAGED) {
+            __syncthreads();                                          // every byte has been read: the lines may be written
+            rows_ready = u + 1 < u_end;
+            if (rows_ready) issue_rows(u + 1);                        // in flight across all the passes of this unit
+        }
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int g = threadIdx.x + T * it;
+            if (g < total0) {
+                const int c = g / m0, j = g - c * m0;
+                Bfly<R0, false>::run(v0[it]);
+                float2* zc = z + c * zs;
+                zc[PL::at(j)] = v0[it][0];
+#pragma unroll
+                for (int q = 1; q < R0; ++q) zc[PL::at(j + q * m0)] = cmul(v0[it][q], tw0l[(q - 1) * m0 + j]);
+            }
+        }
+        __syncthreads();
+        fk_inner_passes<PL, 1, CH, T, false>(z, zs, twl);
+        fk_mid_lds<PL, T, CH>(z, zs, mpl);
+        __syncthreads();
+        fk_inner_passes<PL, P - 2, CH, T, true>(z, zs, twl);
+        // ---- inverse pass 0: LDS -> conj twiddle -> butterfly -> cropped float rows
+        const size_t strip_step = static_cast<size_t>(npairs) * (2 * tile_w);
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int g = threadIdx.x + T * it;
+            if (g < total0) {
+                const int c = g / m0, j = g - c * m0;
+                const float2* zc = z + c * zs;
+                float* out_a = out_u + static_cast<size_t>(c) * plane_elems;
+                float2 v[R0];
+                v[0] = zc[PL::at(j)];
+#pragma unroll
+                for (int q = 1; q < R0; ++q) v[q] = cmulc(zc[PL::at(j + q * m0)], tw0l[(q - 1) * m0 + j]);
+                Bfly<R0, true>::run(v);
+#pragma unroll
+                for (int k = 0; k < R0; ++k) {
+                    const int x = j + k * m0 - pad;
+                    if (x >= 0 && x < cols) {
+                        if constexpr (tile_shift != 0) {
+                            *reinterpret_cast<float2*>(out_a + (x >> tile_shift) * strip_step + 2 * (x & (tile_w - 1))) = v[k];
+                        } else {
+                            out_a[x] = v[k].x;
+                            if (two) out_a[cols + x] = v[k].y;
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ======================================================================================
 // column pass
 // ======================================================================================
 template <class PL, int T, int C, int CH, bool tiled, bool WL>
@@ -1044,21 +1206,41 @@ template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uin
                                                const float2* tw, const float* mperm)
 {
     if (tile_w != 0 && tile_w != 8) return hipErrorInvalidValue;
-    const size_t lds = fk_row_lds<PL>();
-    auto kern = tile_w ? fast_rowpass_u8<PL, T, 3, 3> : fast_rowpass_u8<PL, T, 3, 0>;
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-        if (e != hipSuccess) return e;
-    }
     const int npairs = (rows + 1) / 2, nunits = npairs * nframes;
-    // resident workgroups per CU: LDS, and PL::row_waves waves on each of the 4 SIMDs
-    int per_cu = static_cast<int>((160 * 1024) / lds);
-    const int by_waves = PL::row_waves * 4 / ((T + 63) / 64);
-    if (per_cu > by_waves) per_cu = by_waves;
-    if (per_cu < 1) per_cu = 1;
-    const int grid = fk_balanced_grid(nunits, kNumCUs * per_cu);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, src, planes, rows, cols, pad, npairs, nunits, tw, mperm);
-    return hipGetLastError();
+    if constexpr (PL::row_channels_together) {
+        const size_t lds = fk_row3_lds<PL, 3>();
+        // the staged input needs 16-byte aligned rows (aligned 16-byte loads that never leave a row)
+        const bool staged = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ((static_cast<size_t>(cols) * 3) & 15) == 0;
+        auto kern = staged ? (tile_w ? fast_rowpass3_u8<PL, T, 3, 3, true> : fast_rowpass3_u8<PL, T, 3, 0, true>)
+                           : (tile_w ? fast_rowpass3_u8<PL, T, 3, 3, false> : fast_rowpass3_u8<PL, T, 3, 0, false>);
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+        }
+        int per_cu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, T, lds) != hipSuccess || per_cu < 1) {
+            (void)hipGetLastError();
+            per_cu = 1;
+        }
+        const int grid = fk_balanced_grid(nunits, kNumCUs * per_cu);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, src, planes, rows, cols, pad, npairs, nunits, tw, mperm);
+        return hipGetLastError();
+    } else {
+        const size_t lds = fk_row_lds<PL>();
+        auto kern = tile_w ? fast_rowpass_u8<PL, T, 3, 3> : fast_rowpass_u8<PL, T, 3, 0>;
+        if (lds > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+            if (e != hipSuccess) return e;
+        }
+        // resident workgroups per CU: LDS, and PL::row_waves waves on each of the 4 SIMDs
+        int per_cu = static_cast<int>((160 * 1024) / lds);
+        const int by_waves = PL::row_waves * 4 / ((T + 63) / 64);
+        if (per_cu > by_waves) per_cu = by_waves;
+        if (per_cu < 1) per_cu = 1;
+        const int grid = fk_balanced_grid(nunits, kNumCUs * per_cu);
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, src, planes, rows, cols, pad, npairs, nunits, tw, mperm);
+        return hipGetLastError();
+    }
 }
 
 template <class PL, int T, int C, bool WL> hipError_t fk_launch_col_u8_c(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,

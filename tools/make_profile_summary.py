@@ -5,11 +5,12 @@ numbers are judged against into profiles/ (tracked) and derives profiles/pmc_tra
 HBM traffic per launch = FETCH_SIZE * f + WRITE_SIZE (rocprofv3 reports KB), collected in SEPARATE
 --pmc passes (MI355X_MICROARCH.md "rocprofv3 PMC slots").  gfx950 correction (same guide, "HBM"):
 FETCH_SIZE tallies 128-byte requests at 64 bytes, i.e. reads exactly half the bytes of wide line
-fills, so f = 2 for the column pass (its 8-byte-per-lane strip gather is served by 128-byte line
-fills: with f = 2 the read side lands on the known byte count of the float planes + the reflected
-border rows).  The row pass reads u8 with byte loads; its FETCH_SIZE is within 11 % of the known
-input bytes with f = 1 and is reported uncorrected.  WRITE_SIZE is exact for streaming stores."""
-import csv, glob, json, os, shutil, sys, collections
+fills, so f = 2 for the column pass (its 16-byte-per-lane strip gather is served by 128-byte line
+fills: with f = 2 the read side lands on the known byte count of the float planes) and for
+fast_rowpass3_u8 (whole u8 rows by 16-byte loads).  fast_rowpass_u8 reads u8 with byte loads; its
+FETCH_SIZE is within 11 % of the known input bytes with f = 1 and is reported uncorrected.
+WRITE_SIZE is exact for streaming stores."""
+import csv, glob, json, os, re, shutil, sys, collections
 
 src, tag = sys.argv[1], sys.argv[2]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -31,7 +32,8 @@ def mean_counters(sub):
     for f in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            name = "fast_rowpass_u8" if "rowpass" in k else "fast_colpass_u8" if "colpass" in k else None
+            m = re.search(r"(fast_(?:row|col)pass\d*_u8)", k)
+            name = m.group(1) if m else None
             if name:
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
     return {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}, \
@@ -48,8 +50,11 @@ json.dump(summary, open(os.path.join(out, "%s_pmc_counters.json" % tag), "w"), i
 frames_per_launch = float(sys.argv[3]) if len(sys.argv) > 3 else 2.0
 px = 2160 * 3840
 traffic = {}
-for k, f in (("fast_rowpass_u8", 1.0), ("fast_colpass_u8", 2.0)):
-    if k in summary and "FETCH_SIZE" in summary[k] and "WRITE_SIZE" in summary[k]:
+for k in sorted(summary):
+    # wide (16-byte per lane, whole-line) reads are the ones FETCH_SIZE halves: the column gather and the staged
+    # row input of fast_rowpass3_u8; the byte loads of fast_rowpass_u8 are reported uncorrected
+    f = 1.0 if k == "fast_rowpass_u8" else 2.0
+    if "FETCH_SIZE" in summary[k] and "WRITE_SIZE" in summary[k]:
         fetch, write = summary[k]["FETCH_SIZE"] * 1024, summary[k]["WRITE_SIZE"] * 1024
         traffic[k] = {
             "frames_per_launch": frames_per_launch,
