@@ -784,13 +784,28 @@ __global__ __launch_bounds__(T) void fast_rowpass3_u8(const uint8_t* __restrict_
             int idx = threadIdx.x + T * k;
             idx = idx < 2 * nchunk ? idx : 2 * nchunk - 1;
             const int rb = idx >= nchunk ? 1 : 0;
+#ifdef FK_ABL_NOLOAD    // ablation build: no global reads (timing only, results are wrong)
+            pfr[k] = fk_u32x4{ static_cast<unsigned>(idx), static_cast<unsigned>(uu), 3u, static_cast<unsigned>(second) };
+#else
             pfr[k] = *reinterpret_cast<const fk_u32x4*>(a + (rb ? second : 0) + 16 * (idx - rb * nchunk));
+#endif
         }
     };
-    bool rows_ready = false;
+    // "claim": make the compiler wait for the prefetched rows HERE.  vmcnt retires in order and the number of
+    // stores a unit issues is not known at compile time, so a wait for these loads that came after stores -- or at a
+    // join of a path with pending loads and one without -- would drain every store in flight.  With the rows
+    // claimed before the stores on every path, the loop carries only stores across its back edge.
+    auto claim_rows = [&]() {
+#pragma unroll
+        for (int k = 0; k < KP; ++k) asm volatile("" ::"v"(pfr[k].x), "v"(pfr[k].y), "v"(pfr[k].z), "v"(pfr[k].w));
+    };
 
     const int u_begin = static_cast<int>(static_cast<long long>(blockIdx.x) * nunits / gridDim.x);
     const int u_end = static_cast<int>(static_cast<long long>(blockIdx.x + 1) * nunits / gridDim.x);
+    if constexpr (STAGED) {
+        if (u_begin < u_end) issue_rows(u_begin);
+        claim_rows();
+    }
     for (int u = u_begin; u < u_end; ++u) {
         const int f = u / npairs, pair = u - f * npairs;
         const int r0 = 2 * pair;
@@ -801,7 +816,6 @@ __global__ __launch_bounds__(T) void fast_rowpass3_u8(const uint8_t* __restrict_
                        (tile_shift ? static_cast<size_t>(pair) * (2 * tile_w) : static_cast<size_t>(r0) * cols);
         __syncthreads();   // the previous unit's readers are done with z (and the tables are visible)
         if constexpr (STAGED) {
-            if (!rows_ready) issue_rows(u);
             const int nchunk = rowbytes >> 4;
 #pragma unroll
             for (int k = 0; k < KP; ++k) {
@@ -816,6 +830,10 @@ __global__ __launch_bounds__(T) void fast_rowpass3_u8(const uint8_t* __restrict_
         for (int it = 0; it < IT0; ++it) {
             int g = threadIdx.x + T * it;
             g = g < total0 ? g : total0 - 1;
+            // opaque to the optimiser: otherwise the 2*R0 per-thread byte offsets (and, below, the R0 store offsets)
+            // are hoisted out of the unit loop, held in registers for its whole length and partly spilled -- and
+            // every spill reload waits for ALL outstanding global loads and stores (vmcnt is in order)
+            asm volatile("" : "+v"(g));
             const int c = g / m0, j = g - c * m0;
             uint8_t pa[R0], pb[R0];
             bool ok[R0];
@@ -838,8 +856,7 @@ __global__ __launch_bounds__(T) void fast_rowpass3_u8(const uint8_t* __restrict_
         }
         if constexpr (STAGED) {
             __syncthreads();                                          // every byte has been read: the lines may be written
-            rows_ready = u + 1 < u_end;
-            if (rows_ready) issue_rows(u + 1);                        // in flight across all the passes of this unit
+            if (u + 1 < u_end) issue_rows(u + 1);                     // in flight across all the passes of this unit
         }
 #pragma unroll
         for (int it = 0; it < IT0; ++it) {
@@ -859,14 +876,20 @@ __global__ __launch_bounds__(T) void fast_rowpass3_u8(const uint8_t* __restrict_
         __syncthreads();
         fk_inner_passes<PL, P - 2, CH, T, true>(z, zs, twl);
         // ---- inverse pass 0: LDS -> conj twiddle -> butterfly -> cropped float rows
-        const size_t strip_step = static_cast<size_t>(npairs) * (2 * tile_w);
+        if constexpr (STAGED) claim_rows();      // before this unit's stores (see claim_rows)
+        // offsets inside a plane are 32-bit (the launcher checks plane_elems < 2^31): sixteen 64-bit per-thread
+        // offsets kept across the unit loop were what spilled, and every spill reload drains the memory queue
+        const int strip_step = npairs * (2 * tile_w);
 #pragma unroll
         for (int it = 0; it < IT0; ++it) {
-            const int g = threadIdx.x + T * it;
+            int g = threadIdx.x + T * it;
+            asm volatile("" : "+v"(g));
             if (g < total0) {
                 const int c = g / m0, j = g - c * m0;
                 const float2* zc = z + c * zs;
-                float* out_a = out_u + static_cast<size_t>(c) * plane_elems;
+                // byte offset from the unit's (uniform) base in 32 bits: one address register per store, 24-bit multiply
+                const unsigned cbase = static_cast<unsigned>(c) * static_cast<unsigned>(plane_elems);
+                char* const out_b = reinterpret_cast<char*>(out_u);
                 float2 v[R0];
                 v[0] = zc[PL::at(j)];
 #pragma unroll
@@ -875,12 +898,21 @@ __global__ __launch_bounds__(T) void fast_rowpass3_u8(const uint8_t* __restrict_
 #pragma unroll
                 for (int k = 0; k < R0; ++k) {
                     const int x = j + k * m0 - pad;
-                    if (x >= 0 && x < cols) {
+#ifdef FK_ABL_NOSTORE   // ablation build: no global writes, values kept alive
+                    asm volatile("" ::"v"(v[k].x), "v"(v[k].y), "v"(x));
+                    if (false)
+#else
+                    if (x >= 0 && x < cols)
+#endif
+                    {
                         if constexpr (tile_shift != 0) {
-                            *reinterpret_cast<float2*>(out_a + (x >> tile_shift) * strip_step + 2 * (x & (tile_w - 1))) = v[k];
+                            const unsigned off = cbase + __umul24(static_cast<unsigned>(x) >> tile_shift, static_cast<unsigned>(strip_step)) +
+                                                 2u * (static_cast<unsigned>(x) & (tile_w - 1));
+                            *reinterpret_cast<float2*>(out_b + off * 4u) = v[k];
                         } else {
-                            out_a[x] = v[k].x;
-                            if (two) out_a[cols + x] = v[k].y;
+                            const unsigned off = cbase + static_cast<unsigned>(x);
+                            *reinterpret_cast<float*>(out_b + off * 4u) = v[k].x;
+                            if (two) *reinterpret_cast<float*>(out_b + (off + static_cast<unsigned>(cols)) * 4u) = v[k].y;
                         }
                     }
                 }
@@ -956,7 +988,6 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
     const int n_items = npairs * C;
     constexpr int KG = tiled ? ((N / 2) * C + T - 1) / T : 1;      // rows <= N - 2 pad  =>  npairs <= N/2
     float4 pf[KG];
-    bool pf_valid = false;
     auto issue_gather = [&](int uu, int cc) {
         const int ff = uu / nstrips, ss = uu - ff * nstrips;
         const float* sb = planes0 + (static_cast<size_t>(ff) * CH + cc) * plane_elems + static_cast<size_t>(ss) * npairs * (2 * G);
@@ -1019,6 +1050,17 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
         if (part == 2) pend_x0 = -1;
     };
 
+    // "claim" = make the compiler wait for the prefetched strip at a chosen point (see fast_rowpass3_u8): before the
+    // write-out stores on every path, so that the loop carries only stores across its back edge and no wait for a
+    // load ever has to cover them
+    auto claim_gather = [&]() {
+#pragma unroll
+        for (int k = 0; k < KG; ++k) asm volatile("" ::"v"(pf[k].x), "v"(pf[k].y), "v"(pf[k].z), "v"(pf[k].w));
+    };
+    if constexpr (tiled && FK_COL_PREFETCH) {
+        if (u_begin + lane_in_xcd < u_end) issue_gather(u_begin + lane_in_xcd, 0);
+        claim_gather();
+    }
     for (int u = u_begin + lane_in_xcd; u < u_end; u += wg_in_xcd) {
         const int f = u / nstrips, strip = u - f * nstrips;
         planes = planes0 + static_cast<size_t>(f) * plane_elems * CH;
@@ -1032,7 +1074,7 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
             // ---- gather: line l, position p  <-  plane[reflect(p)][x0 + 2l .. +1]
             const bool full = x0 + G <= cols && (cols & 1) == 0;
             if constexpr (tiled) {
-                if (!pf_valid) issue_gather(u, ch);        // first task of this workgroup, or prefetch disabled
+                if constexpr (!FK_COL_PREFETCH) issue_gather(u, ch);
                 commit_gather(x0);
             } else if (full) {
                 // unconditional 8-byte loads (clamped row, masked value): the unrolled loop keeps
@@ -1059,8 +1101,7 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
             __syncthreads();
             if constexpr (tiled && FK_COL_PREFETCH) {
                 const int nu = ch + 1 < CH ? u : u + wg_in_xcd, nch = ch + 1 < CH ? ch + 1 : 0;
-                pf_valid = nu < u_end;
-                if (pf_valid) issue_gather(nu, nch);
+                if (nu < u_end) issue_gather(nu, nch);
             }
             if (FK_COL_DEFER_WRITEOUT && ch == 0) writeout_part(0);
             // ---- pass 0 (register twiddles)
@@ -1131,6 +1172,7 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
         }
         FK_STAMP(7);           // inverse pass 0 + pixel stage
         __syncthreads();
+        if constexpr (tiled && FK_COL_PREFETCH) claim_gather();   // before the stores below
         // ---- write the strip as whole pixels: G*CH contiguous bytes per image row
         constexpr int RB = G * CH;
         if (FK_COL_DEFER_WRITEOUT && x0 + G <= cols && ((cols * CH) & 7) == 0 && (RB & 7) == 0) {
@@ -1208,6 +1250,8 @@ template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uin
     if (tile_w != 0 && tile_w != 8) return hipErrorInvalidValue;
     const int npairs = (rows + 1) / 2, nunits = npairs * nframes;
     if constexpr (PL::row_channels_together) {
+        // 32-bit BYTE offsets inside a frame's three float planes, strip_step below 2^24 for the 24-bit multiply
+        if (static_cast<size_t>(rows + 1) * (cols + 8) * 12 >= (static_cast<size_t>(1) << 32) || rows >= (1 << 20)) return hipErrorInvalidValue;
         const size_t lds = fk_row3_lds<PL, 3>();
         // the staged input needs 16-byte aligned rows (aligned 16-byte loads that never leave a row)
         const bool staged = (reinterpret_cast<uintptr_t>(src) & 15) == 0 && ((static_cast<size_t>(cols) * 3) & 15) == 0;
