@@ -114,6 +114,10 @@ template <int N_, int FLAGS_, int... Rs> struct StaticPlan {
     static constexpr int hoist_max = (FLAGS_ & 2) ? (FK_HOIST_MAX_R < 10 ? FK_HOIST_MAX_R : 10) : FK_HOIST_MAX_R;
     static constexpr bool tw0_lds = (FLAGS_ & 4) != 0;
     static constexpr int col_min_waves = (FLAGS_ & 8) ? 3 : 1;
+#ifndef FK_COL_OPAQUE
+#define FK_COL_OPAQUE 15
+#endif
+    static constexpr int col_opaque = (FLAGS_ & 64) ? FK_COL_OPAQUE : 0;   // 64: keep per-thread offsets out of the loop-invariant set (bit per site)
     static constexpr int row_waves = (FLAGS_ & 16) ? 4 : FK_ROW_WAVES_PER_SIMD;
     static constexpr bool row_channels_together = (FLAGS_ & 32) != 0;
     static __host__ __device__ constexpr int at(int i) { return PAD ? i + (i >> 5) : i; }
@@ -991,9 +995,13 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
     auto issue_gather = [&](int uu, int cc) {
         const int ff = uu / nstrips, ss = uu - ff * nstrips;
         const float* sb = planes0 + (static_cast<size_t>(ff) * CH + cc) * plane_elems + static_cast<size_t>(ss) * npairs * (2 * G);
+        // the thread index is made opaque wherever per-thread offsets follow from it: otherwise they are hoisted out of
+        // the unit loop, one or two registers each, and the kernel drowns in loop invariants (fast_rowpass3_u8: 168 -> 102 VGPRs)
+        int tid = threadIdx.x;
+        if constexpr ((PL::col_opaque & 1) != 0) asm volatile("" : "+v"(tid));
 #pragma unroll
         for (int k = 0; k < KG; ++k) {
-            int idx = threadIdx.x + T * k;
+            int idx = tid + T * k;
             idx = idx < n_items ? idx : n_items - 1;
             const int q = idx / C, l = idx - q * C;
 #ifdef FK_ABL_NOLOAD
@@ -1004,9 +1012,11 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
         }
     };
     auto commit_gather = [&](int xx0) {
+        int tid = threadIdx.x;
+        if constexpr ((PL::col_opaque & 2) != 0) asm volatile("" : "+v"(tid));
 #pragma unroll
         for (int k = 0; k < KG; ++k) {
-            const int idx = threadIdx.x + T * k;
+            const int idx = tid + T * k;
             if (idx < n_items) {
                 const int q = idx / C, l = idx - q * C;
                 const int col = xx0 + 2 * l;
@@ -1108,7 +1118,8 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
             if (p0_active) {
 #pragma unroll
                 for (int it = 0; it < IT0; ++it) {
-                    const int j = j0 + T * it;
+                    int j = j0 + T * it;
+                    if constexpr ((PL::col_opaque & 4) != 0) asm volatile("" : "+v"(j));
                     if (j < m0) {
 #pragma unroll 1
                         for (int c = gi; c < C; c += K) {
@@ -1146,7 +1157,8 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
             if (p0_active) {
 #pragma unroll
                 for (int it = 0; it < IT0; ++it) {
-                    const int j = j0 + T * it;
+                    int j = j0 + T * it;
+                    if constexpr ((PL::col_opaque & 8) != 0) asm volatile("" : "+v"(j));
                     if (j < m0) {
 #pragma unroll 1
                         for (int c = gi; c < C; c += K) {
