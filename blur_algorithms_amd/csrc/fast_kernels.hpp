@@ -740,10 +740,10 @@ __global__ __launch_bounds__(T, PL::row_waves) void fast_rowpass_u8(const uint8_
 // One workgroup per CU transforms the CH complex lines of a row pair (one per channel) at once, flattened over
 // (channel, butterfly) in every pass -- the column kernel's recipe: many waves in ONE workgroup, every pass close to
 // one full round of butterflies, pass 0's twiddles in LDS so that no pass pins registers across the others.
-// LDS: CH lines | inner twiddles | multipliers | pass-0 twiddles.
+// LDS: CH lines | inner twiddles | pass-0 twiddles (plan flag 4 only; else registers) | multipliers.
 template <class PL, int CH> __host__ __device__ constexpr size_t fk_row3_lds()
 {
-    return (static_cast<size_t>(CH) * PL::zs() + ((PL::lds_tw_count() + 1) & ~1) + static_cast<size_t>(PL::R[0] - 1) * PL::m(0)) * sizeof(float2) +
+    return (static_cast<size_t>(CH) * PL::zs() + ((PL::lds_tw_count() + 1) & ~1) + (PL::tw0_lds ? static_cast<size_t>(PL::R[0] - 1) * PL::m(0) : 0)) * sizeof(float2) +
            static_cast<size_t>(PL::N) * sizeof(float);
 }
 
@@ -761,13 +761,31 @@ __global__ __launch_bounds__(T) void fast_rowpass3_u8(const uint8_t* __restrict_
     float2* z = reinterpret_cast<float2*>(smem);
     float2* twl = z + CH * zs;
     float2* tw0l = twl + ((PL::lds_tw_count() + 1) & ~1);
-    float* mpl = reinterpret_cast<float*>(tw0l + (R0 - 1) * m0);
+    float* mpl = reinterpret_cast<float*>(tw0l + (PL::tw0_lds ? (R0 - 1) * m0 : 0));
     constexpr int tile_w = tile_shift ? 1 << tile_shift : 0;
     const size_t plane_elems = tile_shift ? static_cast<size_t>((cols + tile_w - 1) >> tile_shift) * npairs * (2 * tile_w)
                                           : static_cast<size_t>(rows) * cols;
     for (int i = threadIdx.x; i < PL::lds_tw_count(); i += T) twl[i] = tw[PL::lds_tw_begin() + i];
-    for (int i = threadIdx.x; i < (R0 - 1) * m0; i += T) tw0l[i] = tw[i];
+    if constexpr (PL::tw0_lds) {
+        for (int i = threadIdx.x; i < (R0 - 1) * m0; i += T) tw0l[i] = tw[i];
+    }
     for (int i = threadIdx.x; i < N; i += T) mpl[i] = mperm[i];
+    // plan flag 4 clear: pass 0's twiddles in registers instead (butterfly (c, j) of pass 0 is this thread's in every unit)
+    float2 w0[IT0][R0];
+    if constexpr (!PL::tw0_lds) {
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            int g = threadIdx.x + T * it;
+            g = g < total0 ? g : total0 - 1;
+            const int j = g % m0;
+#pragma unroll
+            for (int q = 1; q < R0; ++q) w0[it][q] = tw[(q - 1) * m0 + j];
+        }
+    }
+    auto p0w = [&](int it, int q, int j) -> float2 {
+        if constexpr (PL::tw0_lds) return tw0l[(q - 1) * m0 + j];
+        else return w0[it][q];
+    };
 
     // STAGED (rows 16-byte aligned, checked by the launcher): the two u8 rows of a unit arrive by 16-byte loads
     // that were issued into registers while the previous unit was being transformed, are parked in the (then free)
@@ -871,7 +889,7 @@ __global__ __launch_bounds__(T) void fast_rowpass3_u8(const uint8_t* __restrict_
                 float2* zc = z + c * zs;
                 zc[PL::at(j)] = v0[it][0];
 #pragma unroll
-                for (int q = 1; q < R0; ++q) zc[PL::at(j + q * m0)] = cmul(v0[it][q], tw0l[(q - 1) * m0 + j]);
+                for (int q = 1; q < R0; ++q) zc[PL::at(j + q * m0)] = cmul(v0[it][q], p0w(it, q, j));
             }
         }
         __syncthreads();
@@ -897,7 +915,7 @@ __global__ __launch_bounds__(T) void fast_rowpass3_u8(const uint8_t* __restrict_
                 float2 v[R0];
                 v[0] = zc[PL::at(j)];
 #pragma unroll
-                for (int q = 1; q < R0; ++q) v[q] = cmulc(zc[PL::at(j + q * m0)], tw0l[(q - 1) * m0 + j]);
+                for (int q = 1; q < R0; ++q) v[q] = cmulc(zc[PL::at(j + q * m0)], p0w(it, q, j));
                 Bfly<R0, true>::run(v);
 #pragma unroll
                 for (int k = 0; k < R0; ++k) {
