@@ -1199,10 +1199,12 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
                     }
                 }
             }
+            // the strip requested at the start of this task has long arrived: claim it at the end of EVERY task, so that
+            // no path reaches the next commit (or the next request, which reuses the registers) with loads pending
+            if constexpr (tiled && FK_COL_PREFETCH) claim_gather();
         }
         FK_STAMP(7);           // inverse pass 0 + pixel stage
         __syncthreads();
-        if constexpr (tiled && FK_COL_PREFETCH) claim_gather();   // before the stores below
         // ---- write the strip as whole pixels: G*CH contiguous bytes per image row
         constexpr int RB = G * CH;
         if (FK_COL_DEFER_WRITEOUT && x0 + G <= cols && ((cols * CH) & 7) == 0 && (RB & 7) == 0) {
