@@ -270,7 +270,26 @@ __global__ __launch_bounds__(256) void boxcol4_kernel(const uint8_t* __restrict_
     };
     for (int d = -r; d <= r; ++d) add(ys + d, 1);
     emit(ys);
-    for (int y = ys + 1; y < ye; ++y) {
+    int y = ys + 1;
+    if (ys - r - 1 >= 0 && ye + r < h) {                // interior segment: loads of four rows in flight together
+        for (; y + 4 <= ye; y += 4) {
+            uint32_t vi[4], vo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                vi[i] = ip[static_cast<size_t>(y + i + r) * pitch4];
+                vo[i] = ip[static_cast<size_t>(y + i - r - 1) * pitch4];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a0 += static_cast<int>(vi[i] & 0xffu) - static_cast<int>(vo[i] & 0xffu);
+                a1 += static_cast<int>((vi[i] >> 8) & 0xffu) - static_cast<int>((vo[i] >> 8) & 0xffu);
+                a2 += static_cast<int>((vi[i] >> 16) & 0xffu) - static_cast<int>((vo[i] >> 16) & 0xffu);
+                a3 += static_cast<int>(vi[i] >> 24) - static_cast<int>(vo[i] >> 24);
+                emit(y + i);
+            }
+        }
+    }
+    for (; y < ye; ++y) {
         add(y + r, 1);
         add(y - r - 1, -1);
         emit(y);
@@ -303,13 +322,27 @@ __global__ __launch_bounds__(256) void boxrow_kernel(const uint8_t* __restrict__
             const int c = item % C, seg = item / C;
             const int xs = seg * seg_len, xe = min(w, xs + seg_len);
             if (xs >= xe) continue;
-            const uint8_t* s = a + c;
-            uint8_t* d = b + c;
+            // restrict: the sweep reads one buffer and writes the other, so the LDS reads of several steps may be
+            // issued together instead of one read latency per step behind the previous step's store
+            const uint8_t* __restrict__ s = a + c;
+            uint8_t* __restrict__ d = b + c;
             int acc = 0;
             if (xs - r - 1 >= 0 && xe + r < w) {        // interior segment: no reflection anywhere
+#pragma unroll 8
                 for (int x = xs - r; x <= xs + r; ++x) acc += s[x * C];
                 d[xs * C] = static_cast<uint8_t>(static_cast<int>(static_cast<float>(acc) * iarr + 0.5f));
-                for (int x = xs + 1; x < xe; ++x) {
+                int x = xs + 1;
+                for (; x + 8 <= xe; x += 8) {
+                    int in_[8], out_[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { in_[i] = s[(x + i + r) * C]; out_[i] = s[(x + i - r - 1) * C]; }
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        acc += in_[i] - out_[i];
+                        d[(x + i) * C] = static_cast<uint8_t>(static_cast<int>(static_cast<float>(acc) * iarr + 0.5f));
+                    }
+                }
+                for (; x < xe; ++x) {
                     acc += s[(x + r) * C] - s[(x - r - 1) * C];
                     d[x * C] = static_cast<uint8_t>(static_cast<int>(static_cast<float>(acc) * iarr + 0.5f));
                 }
@@ -329,6 +362,102 @@ __global__ __launch_bounds__(256) void boxrow_kernel(const uint8_t* __restrict__
         for (int i = threadIdx.x; i < rb / 4; i += 256) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(a)[i];
     } else {
         for (int i = threadIdx.x; i < rb; i += 256) dst[i] = a[i];
+    }
+}
+
+// All `passes` horizontal sweeps of one image row, four pixels per step.  The row sits in LDS with reflect-101
+// borders written out physically (r + 1 pixels on each side, refreshed after every sweep), so every segment takes
+// the same branch-free path: per group of four pixels the entering and the leaving 4*C bytes are fetched as aligned
+// dwords (+ v_alignbyte with a shift that is uniform for the whole launch), the 4*C outputs leave as C dwords.
+// Against the byte-wise kernel above: 3.3x fewer LDS instructions in the walk, 2.9x fewer in the window set-up, no
+// slow border segments.  Same integer accumulators and the same float rounding, so the bytes are identical.
+template <int C>
+__global__ __launch_bounds__(256) void boxrow4_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out,
+                                                      int w, int r, int passes, int groups_per_thread, int off0, int buf_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    uint8_t* a = reinterpret_cast<uint8_t*>(smem);
+    uint8_t* b = a + buf_bytes;
+    const int rb = w * C;
+    const uint8_t* src = in + static_cast<size_t>(blockIdx.x) * rb;
+    uint8_t* dst = out + static_cast<size_t>(blockIdx.x) * rb;
+    if ((rb & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 3) == 0) {
+        for (int i = threadIdx.x; i < rb / 4; i += 256) reinterpret_cast<uint32_t*>(a + off0)[i] = reinterpret_cast<const uint32_t*>(src)[i];
+    } else {
+        for (int i = threadIdx.x; i < rb; i += 256) a[off0 + i] = src[i];
+    }
+    const float iarr = 1.f / static_cast<float>(r + r + 1);
+    const int xs = static_cast<int>(threadIdx.x) * groups_per_thread * 4;
+    const int ngroups = xs < w ? min(groups_per_thread, (w - xs + 3) / 4) : 0;
+    // byte offsets (mod 4) of the two streams: uniform because xs is a multiple of 4
+    const int sh_in = (r * C) & 3, sh_out = ((-(r + 1)) * C) & 3;
+    for (int p = 0; p < passes; ++p) {
+        __syncthreads();                                     // the row (or the previous sweep) is complete
+        // reflect-101 borders: pixels -(r+1) .. -1 and w .. w+r (the outermost one on the left only ever cancels out)
+        for (int i = threadIdx.x; i < 2 * (r + 1) * C; i += 256) {
+            const int side = i / ((r + 1) * C), k = i - side * (r + 1) * C;
+            const int px = k / C, c = k - px * C;
+            const int x = side ? w + px : -(px + 1);
+            int m = x < 0 ? -x : 2 * (w - 1) - x;
+            m = m < 0 ? 0 : (m > w - 1 ? w - 1 : m);
+            a[off0 + x * C + c] = a[off0 + m * C + c];
+        }
+        __syncthreads();
+        if (ngroups > 0) {
+            const uint32_t* __restrict__ s32 = reinterpret_cast<const uint32_t*>(a);
+            uint32_t* __restrict__ d32 = reinterpret_cast<uint32_t*>(b);
+            // aligned dword index of the byte where a stream's group starts
+            auto stream = [&](int byte_off, int sh, uint32_t (&g)[C]) {
+                const int q = (off0 + byte_off - sh) >> 2;
+                uint32_t t[C + 1];
+#pragma unroll
+                for (int k = 0; k <= C; ++k) t[k] = s32[q + k];
+#pragma unroll
+                for (int k = 0; k < C; ++k) g[k] = __builtin_amdgcn_alignbyte(t[k + 1], t[k], sh);
+            };
+            auto byte_of = [](const uint32_t (&g)[C], int k) -> int { return static_cast<int>((g[k >> 2] >> (8 * (k & 3))) & 0xffu); };
+            int acc[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) acc[c] = 0;
+            // window centred on pixel xs - 1: pixels xs-1-r .. xs-1+r = 2r+1 pixels from the "leaving" stream position
+            {
+                const int np = 2 * r + 1;
+                int px = 0;
+                for (; px + 4 <= np; px += 4) {
+                    uint32_t g[C];
+                    stream((xs - 1 - r + px) * C, sh_out, g);
+#pragma unroll
+                    for (int k = 0; k < 4 * C; ++k) acc[k % C] += byte_of(g, k);
+                }
+                for (; px < np; ++px) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) acc[c] += a[off0 + (xs - 1 - r + px) * C + c];
+                }
+            }
+            for (int gi = 0; gi < ngroups; ++gi) {
+                const int x = xs + 4 * gi;
+                uint32_t gin[C], gout[C], res[C];
+                stream((x + r) * C, sh_in, gin);
+                stream((x - r - 1) * C, sh_out, gout);
+#pragma unroll
+                for (int k = 0; k < C; ++k) res[k] = 0;
+#pragma unroll
+                for (int k = 0; k < 4 * C; ++k) {
+                    acc[k % C] += byte_of(gin, k) - byte_of(gout, k);
+                    const uint32_t v = static_cast<uint32_t>(static_cast<int>(static_cast<float>(acc[k % C]) * iarr + 0.5f)) & 0xffu;
+                    res[k >> 2] |= v << (8 * (k & 3));
+                }
+#pragma unroll
+                for (int k = 0; k < C; ++k) d32[((off0 + x * C) >> 2) + k] = res[k];
+            }
+        }
+        uint8_t* t = a; a = b; b = t;
+    }
+    __syncthreads();
+    if ((rb & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 3) == 0) {
+        for (int i = threadIdx.x; i < rb / 4; i += 256) reinterpret_cast<uint32_t*>(dst)[i] = reinterpret_cast<const uint32_t*>(a + off0)[i];
+    } else {
+        for (int i = threadIdx.x; i < rb; i += 256) dst[i] = a[off0 + i];
     }
 }
 
@@ -1102,7 +1231,23 @@ int blur_fastboxblur_u8_dev(blur_ctx* ctx, uint8_t* d_inout, int w, int h, int c
     };
     // horizontal sweeps: all passes of a row inside LDS when two copies of the row fit
     const size_t row_lds = 2 * ((static_cast<size_t>(w) * channels + 3) & ~static_cast<size_t>(3));
-    if (passes > 0 && row_lds <= kLdsLimit) {
+    // four-pixel-per-step kernel: row + physical reflect borders (r + 1 pixels) + slack for whole groups, twice
+    int r_row = (ksize - 1) / 2;
+    if (r_row > w - 1) r_row = w - 1;
+    const int off0 = ((r_row + 2) * channels + 4 + 15) & ~15;                       // whole aligned dwords left of pixel -(r+1)
+    const int buf_bytes = (off0 + (w + r_row + 8) * channels + 16 + 15) & ~15;       // ... and right of pixel w+r+3
+    if (passes > 0 && (channels == 1 || channels == 3 || channels == 4) && 2 * static_cast<size_t>(buf_bytes) <= kLdsLimit) {
+        const int gpt = ((w + 3) / 4 + 255) / 256;
+        const size_t lds = 2 * static_cast<size_t>(buf_bytes);
+        auto launch = [&](auto kern) -> int {
+            if (int rc = set_lds(ctx, kern, lds)) return rc;
+            hipLaunchKernelGGL(kern, dim3(h), dim3(256), lds, ctx->stream, a, b, w, r_row, passes, gpt, off0, buf_bytes);
+            return BLUR_OK;
+        };
+        int rc = channels == 1 ? launch(boxrow4_kernel<1>) : channels == 3 ? launch(boxrow4_kernel<3>) : launch(boxrow4_kernel<4>);
+        if (rc) return rc;
+        std::swap(a, b);
+    } else if (passes > 0 && row_lds <= kLdsLimit) {
         if (int rc = set_lds(ctx, boxrow_kernel, row_lds)) return rc;
         int r = (ksize - 1) / 2;
         if (r > w - 1) r = w - 1;

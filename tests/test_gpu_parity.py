@@ -391,7 +391,9 @@ def test_batch_of_4k_frames_roundtrip_properties(ctx):
     assert torch.equal(a, b)
 
 
-@pytest.mark.parametrize("w,h,ch,ksize,passes", [(97, 61, 3, 9, 2), (128, 64, 1, 5, 3), (50, 40, 3, 41, 3), (33, 20, 3, 81, 1)])
+@pytest.mark.parametrize("w,h,ch,ksize,passes", [(97, 61, 3, 9, 2), (128, 64, 1, 5, 3), (50, 40, 3, 41, 3), (33, 20, 3, 81, 1),
+                                                 (3, 9, 3, 5, 2), (1, 7, 1, 3, 1), (5, 5, 4, 9, 3), (130, 17, 4, 7, 2), (61, 33, 2, 11, 2),
+                                                 (1030, 12, 3, 43, 3), (1027, 9, 1, 2001, 2), (259, 31, 3, 1, 2), (64, 64, 3, 3, 4)])
 def test_fastboxblur(ctx, w, h, ch, ksize, passes):
     torch = _torch()
     from oracle import oracle as O
