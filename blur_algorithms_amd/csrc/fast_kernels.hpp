@@ -1,37 +1,23 @@
 // fast_kernels.hpp -- compile-time specialised row / column kernels for the FFT lengths the
 // BASELINE configs land on.  Same algorithm and data path as the generic kernels in
 // engine.hip (see there), but the plan (N and its radix sequence) is a template argument so
-// that every stride, trip count and table offset is a constant:
-//   * pass 0's twiddles (the only big table: N(1-1/R0) complex) live in REGISTERS: butterfly
-//     j of pass 0 is always done by the same thread, for every line the workgroup processes;
-//   * the pointwise multipliers of the fused middle pass live in registers the same way;
-//   * the small twiddle tables of the inner passes are copied to LDS once per workgroup;
-//   * row pass: pass 0 reads the u8 pixels straight from global memory (deinterleave +
-//     reflect-101 pad fused, Utils.hpp:159-184 / Source.cpp:525-529) and the last inverse
-//     pass stores the cropped float rows straight to global memory (Source.cpp:536);
-//   * column pass: the last inverse pass applies interleave_BGR's "+0.5f, truncate"
-//     (Utils.hpp:189,204-206) and writes bytes into the LDS pixel stage.
+// that every stride, trip count and table offset is a constant.  Both kernels follow one recipe:
+//   * ONE persistent workgroup of 576-768 threads per CU works on several complex lines at once (row pass: the three
+//     channel lines of a row pair; column pass: the four lines of a strip of 8 columns), every pass flattened over
+//     (line, butterfly), the radix order chosen so that a pass is one round of butterflies wherever possible;
+//   * the next unit's input is requested into registers while this unit is transformed, claimed before this unit's
+//     stores are issued (vmcnt retires in order), and committed to LDS when the line buffer is free;
+//   * pass 0's twiddles live in registers or (plan flag 4) in LDS, the small twiddle tables of the inner passes and
+//     the pointwise multipliers of the fused middle pass in LDS;
+//   * row pass: u8 rows in (deinterleave + reflect-101 pad fused, Utils.hpp:159-184 / Source.cpp:525-529), cropped
+//     float rows out (Source.cpp:536); column pass: the last inverse pass applies interleave_BGR's "+0.5f, truncate"
+//     (Utils.hpp:189,204-206) into an LDS pixel stage that leaves as whole pixels.
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include "fft_engine.hpp"
 
 // tuning knobs (overridable per build for A/B runs: tools/build_variant.sh with VFLAGS)
-#ifndef FK_ROW_WAVES_PER_SIMD
-#define FK_ROW_WAVES_PER_SIMD 3     // __launch_bounds__ second argument of the row kernel
-#endif
-#ifndef FK_ROW_MID_GLOBAL
-#define FK_ROW_MID_GLOBAL 0         // 1: middle-pass multipliers straight from global/L1 instead of LDS
-#endif
-#ifndef FK_ROW_MID_REGS
-#define FK_ROW_MID_REGS 0           // 1: row kernel keeps the middle-pass multipliers of its butterflies in registers
-#endif
-#ifndef FK_ROW_PREFETCH
-#define FK_ROW_PREFETCH 0           // 1: row kernel loads the next line's pixels during the inner passes (packed 4 per register)
-#endif
-#ifndef FK_ROW_TW0_RELOAD
-#define FK_ROW_TW0_RELOAD 0         // 1: row kernel re-reads pass 0's twiddles from global (L1/L2) in pass 0 and its inverse
-#endif                               //    instead of holding them in registers across the inner passes
 #ifndef FK_INNER_BATCH
 #define FK_INNER_BATCH 2            // butterflies of one thread whose LDS reads are issued together (inner passes)
 #endif
@@ -44,16 +30,9 @@
 #ifndef FK_HOIST_MAX_R
 #define FK_HOIST_MAX_R 16           // inner passes up to this radix read their twiddles up front
 #endif
-#ifndef FK_COL_DEFER_WRITEOUT
-#define FK_COL_DEFER_WRITEOUT 0     // 1: spread a strip's pixel stores over the next strip's first channel (measured: no gain, the stores stall their wave wherever they are issued)
-#endif
 #ifndef FK_COL_PREFETCH
 #define FK_COL_PREFETCH 1           // column kernel, strip layout: load the next task's strip into registers during the passes
 #endif
-#ifndef FK_WAVE_LOCAL_ROW
-#define FK_WAVE_LOCAL_ROW 0         // row kernel: 1 = inner passes wave-local (no workgroup barriers between them)
-#endif
-// (the column kernel takes the same choice per plan: BLUR_FAST_COL's WL argument)
 #ifndef FK_GATHER_UNROLL
 #define FK_GATHER_UNROLL 4          // independent strip-gather loads a thread keeps in flight (column kernel)
 #endif
@@ -103,7 +82,6 @@ constexpr int kStampTailFloats = 1 << 16;
 //      passes stride by a multiple of 32 elements need it, and it costs three VALU instructions per LDS address.
 //   2  register diet: inner passes of radix > 10 read their twiddles where they are used instead of up front
 //   4  column kernel: pass 0's twiddles live in LDS (behind the pixel stage) instead of registers
-//  16  row kernel: compile for 4 waves per SIMD (<= 128 VGPRs) instead of FK_ROW_WAVES_PER_SIMD
 //  32  row pass by fast_rowpass3_u8: the three channels of a row pair are transformed together by one workgroup per
 //      CU (pass-0 twiddles in LDS), the way the column kernel treats the four lines of a strip
 //   8  column kernel: compile for 3 waves per SIMD (<= 168 VGPRs) although one workgroup alone would not need it, so
@@ -118,8 +96,6 @@ template <int N_, int FLAGS_, int... Rs> struct StaticPlan {
 #define FK_COL_OPAQUE 15
 #endif
     static constexpr int col_opaque = (FLAGS_ & 64) ? FK_COL_OPAQUE : 0;   // 64: keep per-thread offsets out of the loop-invariant set (bit per site)
-    static constexpr int row_waves = (FLAGS_ & 16) ? 4 : FK_ROW_WAVES_PER_SIMD;
-    static constexpr bool row_channels_together = (FLAGS_ & 32) != 0;
     static __host__ __device__ constexpr int at(int i) { return PAD ? i + (i >> 5) : i; }
     static __host__ __device__ constexpr int zs() { return at(N_) + 1; }
     static constexpr int P = sizeof...(Rs);
@@ -153,13 +129,6 @@ struct FastEntry {
                          const float2* tw, const float* mperm, int C);
     size_t (*col_lds_bytes)(int rows, int C);
 };
-
-// LDS of the row kernel: the line, the inner twiddles, the multipliers; multiple of 16
-template <class PL> __host__ __device__ constexpr size_t fk_row_lds_tables()
-{
-    return (((static_cast<size_t>(PL::zs()) + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) +
-             ((FK_ROW_MID_GLOBAL || FK_ROW_MID_REGS) ? 0 : static_cast<size_t>(PL::N) * sizeof(float))) + 15) & ~static_cast<size_t>(15);
-}
 
 __device__ __forceinline__ int fk_xcd_contiguous(int b, int nwg)
 {
@@ -259,48 +228,8 @@ __device__ __forceinline__ void fk_inner_range(float2* z, int zs, const float2* 
     }
 }
 
-// fused middle: last forward pass (m == 1) * multipliers * first inverse pass.
-// The multipliers of "my" butterflies are in registers (mm), IT_MID iterations of R each.
-template <class PL, int T, int C> struct MidRegs {
-    static constexpr int R = PL::R[PL::P - 1];
-    static constexpr int nb = PL::nb(PL::P - 1);
-    // per line: butterflies b = tid + T*it
-    static constexpr int IT = (nb + T - 1) / T;
-    float mm[IT][R];
-    __device__ __forceinline__ void load(const float* __restrict__ mperm)
-    {
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int b = threadIdx.x + T * it;
-#pragma unroll
-            for (int q = 0; q < R; ++q) mm[it][q] = mperm[(b < nb ? b : nb - 1) * R + q];
-        }
-    }
-    __device__ __forceinline__ void run(float2* z, int zs) const
-    {
-#pragma unroll
-        for (int it = 0; it < IT; ++it) {
-            const int b = threadIdx.x + T * it;
-            if (b < nb) {
-#pragma unroll 1
-                for (int c = 0; c < C; ++c) {
-                    float2* zc = z + c * zs;
-                    float2 v[R];
-#pragma unroll
-                    for (int k = 0; k < R; ++k) v[k] = zc[PL::at(b * R + k)];
-                    FK_BFLY(R, false, v);
-#pragma unroll
-                    for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mm[it][q]);
-                    FK_BFLY(R, true, v);
-#pragma unroll
-                    for (int k = 0; k < R; ++k) zc[PL::at(b * R + k)] = v[k];
-                }
-            }
-        }
-    }
-};
-
-// the same fused middle pass flattened over (line, butterfly), multipliers read from LDS
+// fused middle: last forward pass (m == 1) * multipliers * first inverse pass,
+// flattened over (line, butterfly), multipliers read from LDS
 template <class PL, int T, int C>
 __device__ __forceinline__ void fk_mid_lds(float2* z, int zs, const float* __restrict__ mpl)
 {
@@ -487,255 +416,6 @@ template <class PL, int T> struct Pass0Regs {
 
 // ======================================================================================
 // row pass
-// ======================================================================================
-template <class PL, int T, int CH, int tile_shift>
-__global__ __launch_bounds__(T, PL::row_waves) void fast_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ planes,
-                                                     int rows, int cols, int pad, int npairs, int nunits,
-                                                     const float2* __restrict__ tw, const float* __restrict__ mperm)
-{
-    static_assert(PL::valid(), "radices do not multiply to N");
-    constexpr int N = PL::N, P = PL::P;
-    constexpr int R0 = PL::R[0], m0 = PL::m(0);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float2* z = reinterpret_cast<float2*>(smem);
-    float2* twl = z + PL::zs();
-    const uint8_t* const src0 = src;
-    float* const planes0 = planes;
-    // tile_shift > 0: strip layout [strip][row pair][tile_w columns][2 rows], tile_w = 1 << tile_shift; 0: row-major
-    constexpr int tile_w = tile_shift ? 1 << tile_shift : 0;
-    const size_t plane_elems = tile_shift ? static_cast<size_t>((cols + tile_w - 1) >> tile_shift) * npairs * (2 * tile_w)
-                                          : static_cast<size_t>(rows) * cols;
-    float* mpl = reinterpret_cast<float*>(twl + ((PL::lds_tw_count() + 1) & ~1));
-
-#ifdef FK_STAMPS
-    unsigned long long st_acc[kStampSlots] = {};
-    unsigned long long st_prev = __builtin_amdgcn_s_memtime();
-#endif
-    Pass0Regs<PL, T> p0;
-    p0.load(tw, threadIdx.x);
-    for (int i = threadIdx.x; i < PL::lds_tw_count(); i += T) twl[i] = tw[PL::lds_tw_begin() + i];
-#if FK_ROW_MID_REGS
-    (void)mpl;
-    const float* mid_tab = mperm;
-    MidRegs<PL, T, 1> mid_regs;
-    mid_regs.load(mperm);
-#elif FK_ROW_MID_GLOBAL
-    (void)mpl;
-    const float* mid_tab = mperm;
-#else
-    for (int i = threadIdx.x; i < N; i += T) mpl[i] = mperm[i];
-    const float* mid_tab = mpl;
-#endif
-
-    // persistent workgroup: a contiguous run of (frame, row pair) units, so the register-resident
-    // tables above are loaded once for many lines
-    const int u_begin = static_cast<int>(static_cast<long long>(blockIdx.x) * nunits / gridDim.x);
-    const int u_end = static_cast<int>(static_cast<long long>(blockIdx.x + 1) * nunits / gridDim.x);
-#if FK_ROW_PREFETCH
-    // The u8 pixels of line t+1 are loaded while line t is in its inner passes (where register
-    // pressure is lowest) and packed four to a register before the radix-R0 inverse pass, so the
-    // HBM round trip of a line's input does not stand in front of its first butterfly.
-    constexpr int IT0 = Pass0Regs<PL, T>::IT;
-    constexpr int PK = (R0 + 3) / 4;
-    uint32_t pka[IT0][PK], pkb[IT0][PK];
-    bool have_next = false;
-    auto line_ptr = [&](int uu, int cc, const uint8_t*& a, const uint8_t*& b) {
-        const int ff = uu / npairs, pp = uu - ff * npairs;
-        a = src0 + (static_cast<size_t>(ff) * rows + 2 * pp) * cols * CH + cc;
-        b = a + ((2 * pp + 1 < rows) ? static_cast<size_t>(cols) * CH : 0);
-    };
-#define FK_ROW_ISSUE(PA, PB, LA, LB)                                                        \
-    _Pragma("unroll") for (int it = 0; it < IT0; ++it) {                                    \
-        int jj = threadIdx.x + T * it;                                                      \
-        jj = jj < m0 ? jj : m0 - 1;                                                         \
-        _Pragma("unroll") for (int k = 0; k < R0; ++k) {                                    \
-            const int x = fk_reflect_src(jj + k * m0, pad, cols);                           \
-            const int xi = (x >= 0 ? x : 0) * CH;                                           \
-            LA[it][k] = (PA)[xi];                                                           \
-            LB[it][k] = (PB)[xi];                                                           \
-        }                                                                                   \
-    }
-#define FK_ROW_PACK(LA, LB)                                                                 \
-    _Pragma("unroll") for (int it = 0; it < IT0; ++it)                                      \
-        _Pragma("unroll") for (int w = 0; w < PK; ++w) {                                    \
-            uint32_t va = 0, vb = 0;                                                        \
-            _Pragma("unroll") for (int b = 0; b < 4; ++b)                                   \
-                if (4 * w + b < R0) {                                                       \
-                    va |= static_cast<uint32_t>(LA[it][4 * w + b]) << (8 * b);              \
-                    vb |= static_cast<uint32_t>(LB[it][4 * w + b]) << (8 * b);              \
-                }                                                                           \
-            pka[it][w] = va;                                                                \
-            pkb[it][w] = vb;                                                                \
-        }
-#endif
-
-    for (int u = u_begin; u < u_end; ++u) {
-        const int f = u / npairs, pair = u - f * npairs;
-        src = src0 + static_cast<size_t>(f) * rows * cols * CH;
-        planes = planes0 + static_cast<size_t>(f) * plane_elems * CH;
-        const int r0 = 2 * pair;
-        const bool two = r0 + 1 < rows;
-        const uint8_t* row_a = src + static_cast<size_t>(r0) * cols * CH;
-        const uint8_t* row_b = row_a + (two ? static_cast<size_t>(cols) * CH : 0);
-        for (int c = 0; c < CH; ++c) {
-            FK_STAMP(0);       // prologue (first line) / loop overhead
-            __syncthreads();   // previous line's readers are done with z (and twl is visible)
-            FK_STAMP(1);       // barrier
-#if FK_ROW_PREFETCH
-            if (!have_next) {  // first line of this workgroup: nothing was prefetched
-                uint8_t la[IT0][R0], lb[IT0][R0];
-                const uint8_t *qa, *qb;
-                line_ptr(u, c, qa, qb);
-                FK_ROW_ISSUE(qa, qb, la, lb)
-                FK_ROW_PACK(la, lb)
-            }
-#pragma unroll
-            for (int it = 0; it < IT0; ++it) {
-                const int j = threadIdx.x + T * it;
-                if (j < m0) {
-                    float2 v[R0];
-#pragma unroll
-                    for (int k = 0; k < R0; ++k) {
-                        const bool ok = fk_reflect_src(j + k * m0, pad, cols) >= 0;
-                        const float a = static_cast<float>((pka[it][k >> 2] >> (8 * (k & 3))) & 0xffu);
-                        const float b = static_cast<float>((pkb[it][k >> 2] >> (8 * (k & 3))) & 0xffu);
-                        v[k] = make_float2(ok ? a : 0.f, (ok && two) ? b : 0.f);
-                    }
-                    Bfly<R0, false>::run(v);
-                    z[PL::at(j)] = v[0];
-#pragma unroll
-                    for (int q = 1; q < R0; ++q) z[PL::at(j + q * m0)] = cmul(v[q], p0.w[it][q]);
-                }
-            }
-            FK_STAMP(2);
-            __syncthreads();
-            FK_STAMP(3);
-            // first forward inner pass (the register-hungry one), THEN issue the next line's pixel
-            // loads: they are in flight across the light passes and packed before the last
-            // inverse inner pass
-            fk_inner_range<PL, 1, 1, 1, T, false>(z, 0, twl);
-            uint8_t na[IT0][R0], nb[IT0][R0];
-            {
-                const int nu = c + 1 < CH ? u : u + 1, nc = c + 1 < CH ? c + 1 : 0;
-                have_next = nu < u_end;
-                if (have_next) {
-                    const uint8_t *qa, *qb;
-                    line_ptr(nu, nc, qa, qb);
-                    FK_ROW_ISSUE(qa, qb, na, nb)
-                }
-            }
-            fk_inner_range<PL, 2, P - 2, 1, T, false>(z, 0, twl);
-            fk_mid_lds<PL, T, 1>(z, 0, mid_tab);
-            __syncthreads();
-            fk_inner_range<PL, P - 2, 2, 1, T, true>(z, 0, twl);
-            if (have_next) { FK_ROW_PACK(na, nb) }
-            fk_inner_range<PL, 1, 1, 1, T, true>(z, 0, twl);
-            FK_STAMP(4);
-#else
-            // ---- pass 0: global u8 -> butterfly -> twiddle -> LDS
-#if FK_ROW_TW0_RELOAD
-            p0.load(tw, threadIdx.x);
-#endif
-#pragma unroll
-            for (int it = 0; it < Pass0Regs<PL, T>::IT; ++it) {
-                const int j = threadIdx.x + T * it;
-                if (j < m0) {
-                    // every load is unconditional (clamped index, value masked afterwards) so that
-                    // all 2*R0 of them are in flight together instead of one round trip each
-                    uint8_t pa[R0], pb[R0];
-                    bool ok[R0];
-#pragma unroll
-                    for (int k = 0; k < R0; ++k) {
-                        const int x = fk_reflect_src(j + k * m0, pad, cols);
-                        ok[k] = x >= 0;
-                        const int xi = (x >= 0 ? x : 0) * CH + c;
-#ifdef FK_ABL_NOLOAD    // ablation build: no global reads (timing only, results are wrong)
-                        pa[k] = static_cast<uint8_t>(xi); pb[k] = static_cast<uint8_t>(xi + j);
-#else
-                        pa[k] = row_a[xi];
-                        pb[k] = row_b[xi];
-#endif
-                    }
-                    float2 v[R0];
-#pragma unroll
-                    for (int k = 0; k < R0; ++k)
-                        v[k] = make_float2(ok[k] ? static_cast<float>(pa[k]) : 0.f, (ok[k] && two) ? static_cast<float>(pb[k]) : 0.f);
-                    Bfly<R0, false>::run(v);
-                    z[PL::at(j)] = v[0];
-#pragma unroll
-                    for (int q = 1; q < R0; ++q) z[PL::at(j + q * m0)] = cmul(v[q], p0.w[it][q]);
-                }
-            }
-            FK_STAMP(2);       // pass 0 incl. global loads
-            __syncthreads();
-            FK_STAMP(3);       // barrier
-#endif
-#if !defined(FK_ABL_NOMIDDLE) && !FK_ROW_PREFETCH  // ablation build: only pass 0 and its inverse
-#if FK_WAVE_LOCAL_ROW
-            fk_inner_section_wave<PL, 1, T>(z, 0, twl, mid_tab);
-            __syncthreads();
-            FK_STAMP(4);       // wave-local inner section + barrier
-#else
-            fk_inner_passes<PL, 1, 1, T, false>(z, 0, twl);
-            FK_STAMP(4);       // forward inner passes + their barriers
-#if FK_ROW_MID_REGS
-            mid_regs.run(z, 0);
-#else
-            fk_mid_lds<PL, T, 1>(z, 0, mid_tab);
-#endif
-            __syncthreads();
-            FK_STAMP(5);       // fused middle + barrier
-            fk_inner_passes<PL, P - 2, 1, T, true>(z, 0, twl);
-            FK_STAMP(6);       // inverse inner passes + barriers
-#endif
-#endif
-#if FK_ROW_TW0_RELOAD
-            p0.load(tw, threadIdx.x);
-#endif
-            // ---- inverse pass 0: LDS -> conj twiddle -> butterfly -> cropped float rows
-            float* out_a = planes + static_cast<size_t>(c) * plane_elems + (tile_shift ? static_cast<size_t>(pair) * (2 * tile_w) : static_cast<size_t>(r0) * cols);
-            const size_t strip_step = static_cast<size_t>(npairs) * (2 * tile_w);   // tiled: distance between strips
-#pragma unroll
-            for (int it = 0; it < Pass0Regs<PL, T>::IT; ++it) {
-                const int j = threadIdx.x + T * it;
-                if (j < m0) {
-                    float2 v[R0];
-                    v[0] = z[PL::at(j)];
-#pragma unroll
-                    for (int q = 1; q < R0; ++q) v[q] = cmulc(z[PL::at(j + q * m0)], p0.w[it][q]);
-                    Bfly<R0, true>::run(v);
-#pragma unroll
-                    for (int k = 0; k < R0; ++k) {
-                        const int x = j + k * m0 - pad;
-#ifdef FK_ABL_NOSTORE   // ablation build: no global writes, values kept alive
-                        asm volatile("" ::"v"(v[k].x), "v"(v[k].y), "v"(x));
-#else
-                        if (x >= 0 && x < cols) {
-                            if constexpr (tile_shift != 0) {
-                                // (row a, row b) of this column: one 8-byte store (row b is 0 when the image has no such row)
-                                *reinterpret_cast<float2*>(out_a + (x >> tile_shift) * strip_step + 2 * (x & (tile_w - 1))) = v[k];
-                            } else {
-                                out_a[x] = v[k].x;
-                                if (two) out_a[cols + x] = v[k].y;
-                            }
-                        }
-#endif
-                    }
-                }
-            }
-            FK_STAMP(7);       // inverse pass 0 + global stores
-        }
-    }
-#ifdef FK_STAMPS
-    if (threadIdx.x == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(mperm) + N) + static_cast<size_t>(blockIdx.x) * kStampSlots;
-        for (int i = 0; i < kStampSlots; ++i) o[i] = st_acc[i];
-    }
-#endif
-}
-
-// ======================================================================================
-// row pass, channels together (plan flag 32)
 // ======================================================================================
 // One workgroup per CU transforms the CH complex lines of a row pair (one per channel) at once, flattened over
 // (channel, butterfly) in every pass -- the column kernel's recipe: many waves in ONE workgroup, every pass close to
@@ -1057,27 +737,6 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
         }
     };
 
-    // Deferred write-out: the 24-byte row segments of a finished strip cost one L2 request each
-    // (the slow part is the texture-address unit, not bandwidth), so instead of issuing them in
-    // one burst they are issued in three parts between the phases of the next strip's first
-    // channel, where they overlap with LDS and VALU work.  The stage is only rewritten by that
-    // channel's last pass, after part 2.
-    constexpr int RQ8 = (G * CH) / 8;
-    int pend_x0 = -1;
-    uint8_t* pend_dst = nullptr;
-    auto writeout_part = [&](int part) {
-        if (pend_x0 < 0) return;
-        const int total = rows * RQ8, per = (total + 2) / 3;
-        const int begin = part * per, end = begin + per < total ? begin + per : total;
-        const uint2* s64 = reinterpret_cast<const uint2*>(stage);
-        FK_UNROLL(4)
-        for (int idx = begin + static_cast<int>(threadIdx.x); idx < end; idx += T) {
-            const int r = idx / RQ8, d = idx - r * RQ8;
-            reinterpret_cast<uint2*>(pend_dst + (static_cast<size_t>(r) * cols + pend_x0) * CH)[d] = s64[idx];
-        }
-        if (part == 2) pend_x0 = -1;
-    };
-
     // "claim" = make the compiler wait for the prefetched strip at a chosen point (see fast_rowpass3_u8): before the
     // write-out stores on every path, so that the loop carries only stores across its back edge and no wait for a
     // load ever has to cover them
@@ -1131,7 +790,6 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
                 const int nu = ch + 1 < CH ? u : u + wg_in_xcd, nch = ch + 1 < CH ? ch + 1 : 0;
                 if (nu < u_end) issue_gather(nu, nch);
             }
-            if (FK_COL_DEFER_WRITEOUT && ch == 0) writeout_part(0);
             // ---- pass 0 (register twiddles)
             if (p0_active) {
 #pragma unroll
@@ -1155,10 +813,8 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
             }
             __syncthreads();
             FK_STAMP(2);       // barrier + pass 0 + barrier
-            if (FK_COL_DEFER_WRITEOUT && ch == 0) writeout_part(1);
             if constexpr (WL) {
                 fk_inner_section_wave<PL, C, T>(z, zs, twl, mpl);
-                if (FK_COL_DEFER_WRITEOUT && ch == 0) writeout_part(2);
                 __syncthreads();
                 FK_STAMP(4);   // wave-local inner section + barrier
             } else {
@@ -1167,7 +823,6 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
             fk_mid_lds<PL, T, C>(z, zs, mpl);
             __syncthreads();
             FK_STAMP(5);       // fused middle
-            if (FK_COL_DEFER_WRITEOUT && ch == 0) { writeout_part(2); __syncthreads(); }
             fk_inner_passes<PL, P - 2, C, T, true>(z, zs, twl);
             FK_STAMP(6);       // inverse inner passes
             }
@@ -1207,10 +862,7 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
         __syncthreads();
         // ---- write the strip as whole pixels: G*CH contiguous bytes per image row
         constexpr int RB = G * CH;
-        if (FK_COL_DEFER_WRITEOUT && x0 + G <= cols && ((cols * CH) & 7) == 0 && (RB & 7) == 0) {
-            pend_x0 = x0;                  // issued during the next strip (or flushed after the loop)
-            pend_dst = dst;
-        } else if (x0 + G <= cols && ((cols * CH) & 7) == 0 && (RB & 7) == 0) {
+        if (x0 + G <= cols && ((cols * CH) & 7) == 0 && (RB & 7) == 0) {
             // 8-byte stores: three per image row of the strip
             constexpr int RQ = RB / 8;
             const uint2* s64 = reinterpret_cast<const uint2*>(stage);
@@ -1240,7 +892,6 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
             }
         }
     }
-    for (int part = 0; part < 3; ++part) writeout_part(part);     // the last strip of this workgroup
 #ifdef FK_STAMPS
     FK_STAMP(0);
     if (threadIdx.x == 0) {
@@ -1251,15 +902,6 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
 }
 
 // ---- launchers ---------------------------------------------------------------------------
-#ifndef FK_ROW_LDS_EXTRA
-#define FK_ROW_LDS_EXTRA 0          // diagnostic: extra LDS bytes per row workgroup (forces fewer workgroups per CU)
-#endif
-template <class PL> size_t fk_row_lds()
-{
-    if (FK_ROW_LDS_EXTRA) return FK_ROW_LDS_EXTRA;
-    return fk_row_lds_tables<PL>();
-}
-
 template <class PL, int C> size_t fk_col_lds(int rows)
 {
     return (static_cast<size_t>(C) * PL::zs() + ((PL::lds_tw_count() + 1) & ~1)) * sizeof(float2) +
@@ -1281,7 +923,7 @@ template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uin
 {
     if (tile_w != 0 && tile_w != 8) return hipErrorInvalidValue;
     const int npairs = (rows + 1) / 2, nunits = npairs * nframes;
-    if constexpr (PL::row_channels_together) {
+    {
         // 32-bit BYTE offsets inside a frame's three float planes, strip_step below 2^24 for the 24-bit multiply
         if (static_cast<size_t>(rows + 1) * (cols + 8) * 12 >= (static_cast<size_t>(1) << 32) || rows >= (1 << 20)) return hipErrorInvalidValue;
         const size_t lds = fk_row3_lds<PL, 3>();
@@ -1298,21 +940,6 @@ template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uin
             (void)hipGetLastError();
             per_cu = 1;
         }
-        const int grid = fk_balanced_grid(nunits, kNumCUs * per_cu);
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, src, planes, rows, cols, pad, npairs, nunits, tw, mperm);
-        return hipGetLastError();
-    } else {
-        const size_t lds = fk_row_lds<PL>();
-        auto kern = tile_w ? fast_rowpass_u8<PL, T, 3, 3> : fast_rowpass_u8<PL, T, 3, 0>;
-        if (lds > 64 * 1024) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
-            if (e != hipSuccess) return e;
-        }
-        // resident workgroups per CU: LDS, and PL::row_waves waves on each of the 4 SIMDs
-        int per_cu = static_cast<int>((160 * 1024) / lds);
-        const int by_waves = PL::row_waves * 4 / ((T + 63) / 64);
-        if (per_cu > by_waves) per_cu = by_waves;
-        if (per_cu < 1) per_cu = 1;
         const int grid = fk_balanced_grid(nunits, kNumCUs * per_cu);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, src, planes, rows, cols, pad, npairs, nunits, tw, mperm);
         return hipGetLastError();

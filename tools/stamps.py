@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""read the -DFK_STAMPS phase stamps of the row kernel (diagnostic build only)"""
+"""read the -DFK_STAMPS phase stamps of the column kernel (diagnostic build only; the unit of s_memtime is NOT the shader clock)"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -15,8 +15,7 @@ lib = _lib.load()
 lib.blur_debug_read_stamps.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int]
 nblk = 4096
 buf = np.zeros(nblk * 8, np.uint64)
-for n_fft, names in ((4000, ["prologue/loop", "barrier A", "pass0+gload", "barrier B", "fwd inner", "mid", "inv inner", "inv pass0+store"]),
-                     (2304, ["prologue/loop/writeout", "gather+barriers", "pass0", "last writeout", "fwd inner", "mid", "inv inner", "inv pass0+stage"])):
+for n_fft, names in ((2304, ["prologue/loop/writeout", "gather+barriers", "pass0", "last writeout", "fwd inner", "mid", "inv inner", "inv pass0+stage"]),):
     buf = np.zeros(nblk * 8, np.uint64)
     rc = lib.blur_debug_read_stamps(ctx._h, n_fft, 1 if n_fft == 4000 else 2, buf.ctypes.data, buf.size)
     st = buf.reshape(nblk, 8).astype(np.float64)
