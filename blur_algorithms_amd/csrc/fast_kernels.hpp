@@ -676,10 +676,13 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
     // run of (frame, strip) units and its workgroups walk it INTERLEAVED, so that at any moment
     // they sit on neighbouring strips: a 128-byte line of the float planes (4 strips wide) and of
     // the u8 output (5.3 strips wide) is then touched by all its users while it is still in L2.
-    const int xcd = blockIdx.x & 7, lane_in_xcd = blockIdx.x >> 3;
-    const int wg_in_xcd = (static_cast<int>(gridDim.x) - xcd + 7) >> 3;
-    const int u_begin = static_cast<int>(static_cast<long long>(xcd) * nunits / 8);
-    const int u_end = static_cast<int>(static_cast<long long>(xcd + 1) * nunits / 8);
+    // (fewer than 8 workgroups -- an image a few strips wide: as many runs as there are workgroups, or units would be
+    // assigned to XCD slots nobody occupies)
+    const int nx = gridDim.x < 8 ? static_cast<int>(gridDim.x) : 8;
+    const int xcd = blockIdx.x % nx, lane_in_xcd = blockIdx.x / nx;
+    const int wg_in_xcd = (static_cast<int>(gridDim.x) - xcd + nx - 1) / nx;
+    const int u_begin = static_cast<int>(static_cast<long long>(xcd) * nunits / nx);
+    const int u_end = static_cast<int>(static_cast<long long>(xcd + 1) * nunits / nx);
     // Strip layout only: the gather of task t+1 = (unit, channel) is issued into REGISTERS when
     // the passes of task t start and committed to LDS when they are done, so its ~2 us round
     // trip hides behind the FFT instead of standing in front of it.

@@ -84,6 +84,9 @@ FAST_CASES = [
     (2160, 170, 50.0),    # column 2560
     (1080, 1920, 20.0),   # BASELINE C2 whole: 2304 / 1280
     (1081, 1923, 20.0),   # both passes specialised, odd x odd: ragged last strip in the strip layout
+    (2208, 15, 2.0),      # column 2304 on an image two strips wide: fewer workgroups than XCDs (found by tools/fuzz.py --targeted)
+    (1200, 8, 2.0),       # column 1280, a single strip
+    (40, 2270, 3.0),      # row 2304 with fewer row pairs than CUs
 ]
 
 

@@ -15,6 +15,7 @@ from conftest import assert_u8_parity
 ap = argparse.ArgumentParser()
 ap.add_argument("--seconds", type=float, default=240); ap.add_argument("--seed", type=int, default=1)
 ap.add_argument("--max-side", type=int, default=2600)
+ap.add_argument("--targeted", action="store_true", help="aim one side at the FFT lengths that have specialised kernels")
 a = ap.parse_args()
 rng = np.random.default_rng(a.seed)
 ctx = B.BlurContext(0)
@@ -23,10 +24,25 @@ n = ties = 0
 lengths = set()
 last = time.time()
 while time.time() < t_end:
-    big = rng.random() < 0.25
-    hi = a.max_side if big else 500
-    rows, cols = int(rng.integers(4, hi)), int(rng.integers(4, hi))
-    sigma = float(np.exp(rng.uniform(np.log(0.3), np.log(60.0))))
+    if a.targeted:
+        # one side lands on a specialised length (as row or as column role), the other stays small (cheap oracle)
+        n_target = int(rng.choice([4000, 2304, 4320, 1280, 2560]))
+        sigma = float(rng.choice([2.0, 5.0, 11.0, 20.0, 33.0, 50.0]))
+        long_side = None
+        for _ in range(50):
+            cand = int(rng.integers(max(8, n_target - 400), n_target))
+            if O.pffft_sizing(cand, cand, sigma)["N0"] == n_target:
+                long_side = cand
+                break
+        if long_side is None:
+            continue
+        short = int(rng.integers(8, 260))
+        rows, cols = (short, long_side) if rng.random() < 0.5 else (long_side, short)
+    else:
+        big = rng.random() < 0.25
+        hi = a.max_side if big else 500
+        rows, cols = int(rng.integers(4, hi)), int(rng.integers(4, hi))
+        sigma = float(np.exp(rng.uniform(np.log(0.3), np.log(60.0))))
     s = O.pffft_sizing(rows, cols, sigma)
     if s["pad"] > min(rows, cols) - 1:
         continue
