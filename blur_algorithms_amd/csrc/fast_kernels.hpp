@@ -872,7 +872,11 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
             FK_UNROLL(4)
             for (int idx = threadIdx.x; idx < rows * RQ; idx += T) {
                 const int r = idx / RQ, d = idx - r * RQ;
+#ifdef FK_ABL_STORELOCAL   // ablation build: same store instructions, all into one small (cache-resident) region
+                uint2* o = reinterpret_cast<uint2*>(dst0 + ((static_cast<size_t>(r) * 24 + blockIdx.x * 64) & 0xfff8));
+#else
                 uint2* o = reinterpret_cast<uint2*>(dst + (static_cast<size_t>(r) * cols + x0) * CH);
+#endif
 #ifdef FK_ABL_NOSTORE
                 asm volatile("" ::"v"(s64[idx].x), "v"(s64[idx].y), "v"(o));
 #else
