@@ -749,7 +749,9 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
             while (C >= 2 && fe->col_lds_bytes(rows, C) > kLdsLimit) C /= 2;
             p.col_fast_c = C >= 2 ? C : 0;
         }
-    if (int rc = get_plan(ctx, p.sz.n_row, allow_fast, false, &p.row)) return rc;
+    // the specialised row kernel addresses a frame's three float planes with 32-bit byte offsets (fk_launch_row_u8)
+    const bool row_fast_ok = static_cast<size_t>(rows + 1) * (cols + 8) * 12 < (static_cast<size_t>(1) << 32) && rows < (1 << 20);
+    if (int rc = get_plan(ctx, p.sz.n_row, allow_fast && row_fast_ok, false, &p.row)) return rc;
     if (int rc = get_plan(ctx, p.sz.n_col, allow_fast && p.col_fast_c > 0, true, &p.col)) return rc;
     if (ck) {
         for (int pass = 0; pass < 2; ++pass) {
