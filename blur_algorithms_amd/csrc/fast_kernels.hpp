@@ -130,12 +130,6 @@ struct FastEntry {
     size_t (*col_lds_bytes)(int rows, int C);
 };
 
-__device__ __forceinline__ int fk_xcd_contiguous(int b, int nwg)
-{
-    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
-}
-
 __device__ __forceinline__ int fk_reflect_src(int p, int pad, int len)
 {
     const int i = p - pad;
@@ -214,17 +208,6 @@ __device__ __forceinline__ void fk_inner_passes(float2* z, int zs, const float2*
         fk_inner_pass<PL, I, C, T, INV>(z, zs, twl);
         __syncthreads();
         fk_inner_passes<PL, (INV ? I - 1 : I + 1), C, T, INV>(z, zs, twl);
-    }
-}
-
-// inner passes I, I+-1, ..., LAST (inclusive), each followed by a workgroup barrier
-template <class PL, int I, int LAST, int C, int T, bool INV>
-__device__ __forceinline__ void fk_inner_range(float2* z, int zs, const float2* twl)
-{
-    if constexpr (I >= 1 && I <= PL::P - 2 && (INV ? I >= LAST : I <= LAST)) {
-        fk_inner_pass<PL, I, C, T, INV>(z, zs, twl);
-        __syncthreads();
-        fk_inner_range<PL, (INV ? I - 1 : I + 1), LAST, C, T, INV>(z, zs, twl);
     }
 }
 
