@@ -96,6 +96,8 @@ def main():
                          "reference's test_images tiled to the frame size")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--wave-resident", default="auto", choices=["auto", "on", "off"],
+                    help="A/B: the wave-resident kernels (columns first, N = 256 R0) or the rows-first kernels of round 1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     args = ap.parse_args()
@@ -136,7 +138,8 @@ def main():
     ctx = B.BlurContext(local)
 
     def step():
-        ctx.pffft_(frames, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch)
+        ctx.pffft_(frames, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch,
+                   wave_resident={"auto": None, "on": True, "off": False}[args.wave_resident])
 
     def fence():
         torch.cuda.synchronize(dev)

@@ -58,6 +58,9 @@ SYMBOLS = {
     "blur_interleave_bgr_f32_u8_dev": (C.c_int, [_P, _P, _P, C.c_uint32]),
     "blur_fastboxblur_u8_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "blur_fastboxblur_u8_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "blur_convolve_lines_c32_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
+    "blur_wr_length": (C.c_int, [C.c_int, C.c_int]),
+    "blur_wr_kernel_multipliers": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "blur_malloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
     "blur_free": (C.c_int, [_P, _P]),
     "blur_host_alloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),

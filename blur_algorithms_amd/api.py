@@ -111,7 +111,8 @@ class BlurContext:
         if rc:
             raise BlurError(rc, self._lib.blur_last_error(self._h).decode())
 
-    def _opts(self, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0, row_major_planes=False):
+    def _opts(self, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0, row_major_planes=False,
+              wave_resident=None):
         o = BlurOpts()
         self._lib.blur_opts_default(C.byref(o))
         o.nyquist_quirk = 1 if nyquist_quirk else 0
@@ -119,6 +120,9 @@ class BlurContext:
         o.reserved[0] = 1 if force_generic else 0   # tests: run the run-time-planned kernels even where a specialised one exists
         o.reserved[1] = int(frames_per_launch)
         o.reserved[2] = 1 if row_major_planes else 0
+        # wave-resident kernels (transform length 256 * R0, columns first): None = where they pay (the image fills most
+        # of the transform), False = never, True = wherever the image fits one
+        o.reserved[3] = 0 if wave_resident is None else (2 if wave_resident else 1)
         return o
 
     def use_torch_stream(self):
@@ -143,13 +147,13 @@ class BlurContext:
 
     # -- pffft_(image, sigma): Source.cpp:429-570 -----------------------------------------
     def pffft_(self, image, sigma, out=None, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0,
-               row_major_planes=False):
+               row_major_planes=False, wave_resident=None):
         """Gaussian blur of a BGR/RGB uint8 image [rows, cols, 3] or a batch [n, rows, cols, 3].
 
         torch CUDA tensor: asynchronous on torch's current stream, returns `out`
         (default: in place, like the reference).  numpy array: host round trip, returns a new array.
         """
-        o = self._opts(nyquist_quirk, col_group, force_generic, frames_per_launch, row_major_planes)
+        o = self._opts(nyquist_quirk, col_group, force_generic, frames_per_launch, row_major_planes, wave_resident)
         if isinstance(image, np.ndarray):
             if (image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3 and not image.flags["C_CONTIGUOUS"]
                     and image.strides[2] == 1 and image.strides[1] == 3 and image.strides[0] >= 3 * image.shape[1]):
@@ -176,6 +180,22 @@ class BlurContext:
         n = 1 if t.dim() == 3 else t.shape[0]
         rows, cols = t.shape[-3], t.shape[-2]
         self._check(self._lib.blur_gaussian_u8c3_batch_dev(self._h, t.data_ptr(), dst.data_ptr(), n, rows, cols, float(sigma), C.byref(o)))
+        return dst
+
+    def convolve_lines(self, lines, multipliers, out=None):
+        """lines: CUDA complex64 tensor [nlines, n]; multipliers: n real factors (numpy float32, natural frequency order).
+        Returns IDFT(multipliers * DFT(line)) per line, unnormalised (blur_convolve_lines_c32_dev): the batched form of
+        pffft_transform_ordered / pffft_sorted_optimized_convolution / pffft_transform_ordered (Source.cpp:531-533)."""
+        import torch
+        t = lines
+        if t.dtype != torch.complex64 or not t.is_cuda or not t.is_contiguous() or t.dim() != 2:
+            raise ValueError("expected a contiguous CUDA complex64 tensor [nlines, n]")
+        dst = torch.empty_like(t) if out is None else out
+        m = np.ascontiguousarray(multipliers, np.float32)
+        if m.shape != (t.shape[1],):
+            raise ValueError("one multiplier per frequency")
+        self.use_torch_stream()
+        self._check(self._lib.blur_convolve_lines_c32_dev(self._h, t.data_ptr(), dst.data_ptr(), t.shape[0], t.shape[1], m.ctypes.data))
         return dst
 
     def pinned_empty(self, shape, dtype=np.uint8):

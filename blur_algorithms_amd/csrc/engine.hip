@@ -28,6 +28,7 @@
 #include "fast_registry.hpp"
 #include "fft_engine.hpp"
 #include "host_math.hpp"
+#include "wr_registry.hpp"
 
 using namespace blur_amd;
 
@@ -494,6 +495,11 @@ struct blur_ctx {
     // (plan key, ksize, quirk, sigma bits) -> device multiplier table in position order
     std::map<std::tuple<int, int, int, uint64_t>, float*> spectra;
     std::map<int, float*> last_spectrum;   // n -> most recent table (diagnostic stamp read-back)
+    int num_cus = 256;           // hipDeviceProp_t::multiProcessorCount
+    // wave-resident engine (wr_kernels.hpp): shared 256-point twiddles, pass-0 twiddles per R0, multiplier tables
+    float2* d_w256 = nullptr;
+    std::map<int, float2*> wr_tw0;
+    std::map<std::tuple<int, int, int, int, uint64_t>, float*> wr_spectra;   // (n, n_ref, ksize | -1, quirk, sigma bits | hash)
     float* work = nullptr;       // float planes of one frame
     size_t work_bytes = 0;
     float* work2 = nullptr;      // second set of planes: very tall images only (column pass without the LDS pixel stage)
@@ -711,6 +717,10 @@ struct Prepared {
     int col_fast_c = 0;     // > 0: complex lines per workgroup of the specialised column kernel
     int tile_w = 0;         // > 0: both passes specialised, the float intermediate uses the strip layout
     size_t frame_elems = 0; // floats of intermediate per frame
+    // wave-resident kernels (columns first, then rows) when both passes have one
+    const WrEntry *wr_col = nullptr, *wr_row = nullptr;
+    float2 *wr_tw0_col = nullptr, *wr_tw0_row = nullptr;
+    float *wr_m_col = nullptr, *wr_m_row = nullptr;
 };
 
 // a caller-supplied separable kernel instead of the Gaussian: taps (odd count, centre in the middle)
@@ -722,8 +732,53 @@ struct CustomKernel {
     int box_klen = 0;      // > 0: build the arrays with box_kernel_1d(klen) instead of from taps
 };
 
+// ---- wave-resident engine: tables --------------------------------------------------------------
+static int wr_get_tables(blur_ctx* ctx, const WrEntry* e, float2** tw0)
+{
+    if (!ctx->d_w256) {
+        std::vector<float> w(512);
+        wr_w256(w.data());
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->d_w256), w.size() * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_w256, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+    auto it = ctx->wr_tw0.find(e->r0);
+    if (it == ctx->wr_tw0.end()) {
+        std::vector<float> t(static_cast<size_t>(e->r0 - 1) * kWrS * 2 + 2);
+        wr_tw0(e->r0, t.data());
+        float2* d = nullptr;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), t.size() * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpy(d, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+        it = ctx->wr_tw0.emplace(e->r0, d).first;
+    }
+    *tw0 = it->second;
+    return BLUR_OK;
+}
+
+// multiplier table (natural order, n floats) of the n-periodic kernel `karr`; cached by `key`
+static int wr_get_spectrum(blur_ctx* ctx, const std::tuple<int, int, int, int, uint64_t>& key, const std::vector<float>& karr, int n, int n_ref, bool quirk, float** out)
+{
+    auto it = ctx->wr_spectra.find(key);
+    if (it != ctx->wr_spectra.end()) { *out = it->second; return BLUR_OK; }
+    std::vector<float> m(n);
+    wr_multipliers(karr.data(), n, n_ref, quirk, m.data());
+    float* d = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(float) * n));
+    HIP_TRY(ctx, hipMemcpy(d, m.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+    ctx->wr_spectra[key] = d;
+    *out = d;
+    return BLUR_OK;
+}
+
+static uint64_t fnv1a(const void* data, size_t bytes)
+{
+    uint64_t h = 1469598103934665603ull;
+    const unsigned char* b = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < bytes; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    return h;
+}
+
 static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p, bool u8c3 = true,
-                   const CustomKernel* ck = nullptr)
+                   const CustomKernel* ck = nullptr, bool allow_wr = true)
 {
     if (!ctx) return BLUR_ERR_INVALID;
     if (rows <= 0 || cols <= 0 || (!ck && !(sigma > 0))) return fail(ctx, BLUR_ERR_INVALID, "rows, cols and sigma must be positive");
@@ -742,6 +797,48 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     const bool quirk = opts ? opts->nyquist_quirk != 0 : true;
     p.col_group = opts ? opts->col_group : 0;
     const bool allow_fast = u8c3 && !(opts && opts->reserved[0] == 1);   // reserved[0] = 1: force the generic kernels (tests)
+    // Wave-resident kernels first (reserved[3] = 1 switches them off): both passes need one, and its LDS must hold the image
+    if (allow_fast && allow_wr && !(opts && opts->reserved[3] == 1)) {
+        const WrEntry* wc = find_wr_entry(rows + 2 * p.sz.pad, true);
+        const WrEntry* wr = find_wr_entry(cols + 2 * p.sz.pad, false);
+        // by default only where the image fills at least 3/4 of both transforms (reserved[3] = 2: wherever it fits)
+        const bool pays = opts && opts->reserved[3] == 2 ? true
+                        : (wc && wr && 4 * (rows + 2 * p.sz.pad) >= 3 * wc->r0 * kWrS && 4 * (cols + 2 * p.sz.pad) >= 3 * wr->r0 * kWrS);
+        if (wc && wr && pays && wc->col_lds(rows) <= kLdsLimit && wr->row_lds(cols) <= kLdsLimit &&
+            wr_frame_floats(rows, cols, p.sz.pad) / 3 < (static_cast<size_t>(1) << 30)) {
+            if (int rc = wr_get_tables(ctx, wc, &p.wr_tw0_col)) return rc;
+            if (int rc = wr_get_tables(ctx, wr, &p.wr_tw0_row)) return rc;
+            for (int pass = 0; pass < 2; ++pass) {
+                const WrEntry* e = pass ? wc : wr;
+                const int n = e->r0 * kWrS, n_ref = pass ? p.sz.n_col : p.sz.n_row;
+                std::vector<float> karr(n, 0.f);
+                std::tuple<int, int, int, int, uint64_t> key;
+                if (ck) {
+                    if (ck->box_klen > 0) box_kernel_1d(karr.data(), ck->box_klen, n);
+                    else {
+                        if (ck->ksize > n) return fail(ctx, BLUR_ERR_INVALID, "kernel longer than the padded line");
+                        const int c = ck->ksize / 2;
+                        for (int t = 0; t < ck->ksize; ++t) karr[(t - c + n) % n] += ck->taps[t];
+                    }
+                    key = std::make_tuple(n, n_ref, -1, quirk ? 1 : 0, fnv1a(karr.data(), karr.size() * sizeof(float)));
+                } else {
+                    uint64_t bits;
+                    std::memcpy(&bits, &sigma, sizeof bits);
+                    key = std::make_tuple(n, n_ref, p.sz.kSize, quirk ? 1 : 0, bits);
+                    if (ctx->wr_spectra.find(key) == ctx->wr_spectra.end()) {
+                        std::vector<float> k(std::max(n, p.sz.kSize));
+                        get_gaussian(k.data(), sigma, p.sz.kSize, n);          // Source.cpp:75-102: taps rotated to index 0
+                        std::copy(k.begin(), k.begin() + n, karr.begin());
+                    }
+                }
+                if (int rc = wr_get_spectrum(ctx, key, karr, n, n_ref, quirk, pass ? &p.wr_m_col : &p.wr_m_row)) return rc;
+            }
+            p.wr_col = wc;
+            p.wr_row = wr;
+            p.frame_elems = wr_frame_floats(rows, cols, p.sz.pad);
+            return BLUR_OK;
+        }
+    }
     // the specialised column kernel needs its strip (C complex lines + pixel stage) to fit in LDS
     if (allow_fast)
         if (const FastEntry* fe = find_fast_entry(p.sz.n_col, true)) {
@@ -863,6 +960,15 @@ int blur_kernel_multipliers(double sigma, int ksize, int n, float* m)
     return BLUR_OK;
 }
 
+int blur_wr_kernel_multipliers(double sigma, int ksize, int n, int n_ref, int quirk, float* m)
+{
+    if (!m || !(sigma > 0) || ksize <= 0 || n < ksize || (n & 1) || n_ref <= 0) return BLUR_ERR_INVALID;
+    std::vector<float> k(std::max(n, ksize));
+    get_gaussian(k.data(), sigma, ksize, n);
+    wr_multipliers(k.data(), n, n_ref, quirk != 0, m);
+    return BLUR_OK;
+}
+
 int blur_fft_plan_radices(int n, int* radices)
 {
     FftPlan p;
@@ -886,6 +992,8 @@ int blur_ctx_create(blur_ctx** out, int device)
     if (e != hipSuccess) { g_create_err = std::string("hipSetDevice: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
     blur_ctx* c = new blur_ctx();
     c->device = device;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
     *out = c;
     return BLUR_OK;
 }
@@ -897,6 +1005,9 @@ int blur_ctx_destroy(blur_ctx* ctx)
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->plans) if (kv.second->d_tw) (void)hipFree(kv.second->d_tw);
     for (auto& kv : ctx->spectra) (void)hipFree(kv.second);
+    if (ctx->d_w256) (void)hipFree(ctx->d_w256);
+    for (auto& kv : ctx->wr_tw0) (void)hipFree(kv.second);
+    for (auto& kv : ctx->wr_spectra) (void)hipFree(kv.second);
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->work2) (void)hipFree(ctx->work2);
     if (ctx->box_tmp) (void)hipFree(ctx->box_tmp);
@@ -982,6 +1093,14 @@ static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_
         const int nf = nframes - f < chunk ? nframes - f : chunk;
         const uint8_t* s = d_src + static_cast<size_t>(f) * px * 3;
         uint8_t* d = d_dst + static_cast<size_t>(f) * px * 3;
+        if (p.wr_col) {
+            // columns first, then rows (wr_kernels.hpp); timing slot 1 = column kernel, 0 = row kernel as elsewhere
+            { TimedLaunch t(ctx, 1, nf);
+              HIP_TRY(ctx, p.wr_col->col_u8(ctx->stream, s, ctx->work, rows, cols, p.sz.pad, nf, ctx->num_cus, ctx->d_w256, p.wr_tw0_col, p.wr_m_col)); }
+            { TimedLaunch t(ctx, 0, nf);
+              HIP_TRY(ctx, p.wr_row->row_u8(ctx->stream, ctx->work, d, rows, cols, p.sz.pad, nf, ctx->num_cus, ctx->d_w256, p.wr_tw0_row, p.wr_m_row)); }
+            continue;
+        }
         if (int rc = run_rowpass_u8c3(ctx, s, ctx->work, rows, cols, nf, p, p.tile_w)) return rc;
         if (int rc = run_colpass_u8c3(ctx, ctx->work, d, rows, cols, nf, p)) return rc;
     }
@@ -1058,7 +1177,7 @@ int blur_rowpass_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, float* d_planes, 
     if (!ctx) return BLUR_ERR_INVALID;
     if (!d_src || !d_planes) return fail(ctx, BLUR_ERR_INVALID, "null pointer");
     Prepared p;
-    if (int rc = prepare(ctx, rows, cols, sigma, opts, p)) return rc;
+    if (int rc = prepare(ctx, rows, cols, sigma, opts, p, true, nullptr, false)) return rc;   // the rows-first kernels: row-major planes
     return run_rowpass_u8c3(ctx, d_src, d_planes, rows, cols, 1, p, 0);   // always row-major for the caller
 }
 
@@ -1301,6 +1420,38 @@ int blur_fastboxblur_u8_host(blur_ctx* ctx, uint8_t* inout, int w, int h, int ch
 
 /* diagnostic builds (-DFK_STAMPS): copy the stamp tail behind the multiplier table of FFT length n
    (role 1 = specialised row plan, 2 = specialised column plan) */
+int blur_convolve_lines_c32_dev(blur_ctx* ctx, const float* d_in, float* d_out, int nlines, int n, const float* multipliers)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!d_in || !d_out || !multipliers || nlines < 0 || n <= 0) return fail(ctx, BLUR_ERR_INVALID, "null pointer or non-positive size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const WrEntry* e = nullptr;
+    for (int role = 0; role < 2 && !e; ++role) {
+        const WrEntry* c = find_wr_entry(n, role != 0);
+        if (c && c->r0 * kWrS == n) e = c;
+    }
+    if (!e) return fail(ctx, BLUR_ERR_UNSUPPORTED, "no wave-resident kernel for this length (blur_wr_length)");
+    float2* tw0 = nullptr;
+    if (int rc = wr_get_tables(ctx, e, &tw0)) return rc;
+    const auto key = std::make_tuple(n, 0, -2, 0, fnv1a(multipliers, sizeof(float) * n));
+    float* d_m = nullptr;
+    auto it = ctx->wr_spectra.find(key);
+    if (it != ctx->wr_spectra.end()) d_m = it->second;
+    else {
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_m), sizeof(float) * n));
+        HIP_TRY(ctx, hipMemcpy(d_m, multipliers, sizeof(float) * n, hipMemcpyHostToDevice));
+        ctx->wr_spectra[key] = d_m;
+    }
+    HIP_TRY(ctx, e->lines(ctx->stream, reinterpret_cast<const float2*>(d_in), reinterpret_cast<float2*>(d_out), nlines, ctx->num_cus, ctx->d_w256, tw0, d_m));
+    return BLUR_OK;
+}
+
+int blur_wr_length(int need, int column_role)
+{
+    const WrEntry* e = find_wr_entry(need, column_role != 0);
+    return e ? e->r0 * kWrS : 0;
+}
+
 int blur_debug_read_stamps(blur_ctx* ctx, int n, int role, unsigned long long* out, int count)
 {
     if (!ctx || !out) return BLUR_ERR_INVALID;

@@ -243,4 +243,43 @@ void permuted_multipliers(const FftPlan& plan, const float* m, bool quirk, float
     }
 }
 
+void wr_w256(float* w256)
+{
+    const long double two_pi = 6.283185307179586476925286766559L;
+    for (int m = 0; m < 256; ++m) {
+        const long double a = -two_pi * m / 256;
+        w256[2 * m] = static_cast<float>(cosl(a));
+        w256[2 * m + 1] = static_cast<float>(sinl(a));
+    }
+}
+
+void wr_tw0(int r0, float* tw0)
+{
+    const long double two_pi = 6.283185307179586476925286766559L;
+    const int n = 256 * r0;
+    for (int q = 1; q < r0; ++q)
+        for (int j = 0; j < 256; ++j) {
+            const long double a = -two_pi * static_cast<long double>((j * q) % n) / n;
+            const size_t e = static_cast<size_t>((q - 1) * 256 + j) * 2;
+            tw0[e] = static_cast<float>(cosl(a));
+            tw0[e + 1] = static_cast<float>(sinl(a));
+        }
+}
+
+void wr_multipliers(const float* karr, int n, int n_ref, bool quirk, float* mult)
+{
+    const long double two_pi = 6.283185307179586476925286766559L;
+    std::vector<int> nz;
+    for (int i = 0; i < n; ++i) if (karr[i] != 0.f) nz.push_back(i);
+    long double k0 = 0, kalt = 0;
+    for (int i : nz) { k0 += karr[i]; kalt += (i & 1) ? -static_cast<long double>(karr[i]) : static_cast<long double>(karr[i]); }
+    for (int f = 0; f <= n / 2; ++f) {
+        long double acc = 0;
+        for (int i : nz) acc += static_cast<long double>(karr[i]) * cosl(two_pi * static_cast<long double>((static_cast<long long>(f) * i) % n) / n);
+        if (quirk && f == n / 2) acc = kalt + (k0 - kalt) * static_cast<long double>(n) / n_ref;
+        mult[f] = static_cast<float>(acc / n);
+        if (f > 0 && f < n / 2) mult[n - f] = mult[f];
+    }
+}
+
 }  // namespace blur_amd

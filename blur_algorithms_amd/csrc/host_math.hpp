@@ -62,4 +62,16 @@ bool make_plan_radices(int n, const int* radices, int npass, FftPlan& plan);
 // (Source.cpp:420-425, the imaginary slot of i = 0 holds the Nyquist bin).
 void permuted_multipliers(const FftPlan& plan, const float* m, bool quirk, float* mperm);
 
+// ---- wave-resident engine (wr_kernels.hpp): transform length n = 256 * r0, tables in NATURAL frequency order.
+// w256[m] = exp(-2 pi i m / 256), m = 0..255 (interleaved re, im)
+void wr_w256(float* w256);
+// pass-0 twiddles: tw0[(q-1)*256 + j] = exp(-2 pi i j q / n), q = 1..r0-1, j = 0..255 (interleaved re, im)
+void wr_tw0(int r0, float* tw0);
+// Multipliers of an n-periodic real even kernel `karr` (n floats, centre at index 0), all n bins:
+//   mult[f] = Re DFT_n(karr)[f] / n                                              Source.cpp:423,506-507
+// With `quirk` the reference scales its Nyquist bin (slot 1 of pffft's ordered layout) with the DC gain
+// (Source.cpp:420-425); its transform length is n_ref, ours is n: the extra term (K[0] - K[n_ref/2]) / n_ref is
+// added to bin n/2 (the alternating sum of the taps does not depend on the even length they are wrapped to).
+void wr_multipliers(const float* karr, int n, int n_ref, bool quirk, float* mult);
+
 }  // namespace blur_amd

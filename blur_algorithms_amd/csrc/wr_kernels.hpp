@@ -1,0 +1,662 @@
+// wr_kernels.hpp -- "wave-resident" kernels of the 1D-tiled FFT convolution (Source.cpp:429-570).
+//
+// A line of N = R0 * 256 complex points (two real image lines ride in one complex line, fft_engine.hpp) is
+// transformed in three stages, and only the first and the last touch LDS as a workgroup:
+//   pass 0          radix-R0 decimation-in-frequency butterflies over elements j + 256 k, twiddled, written to LDS
+//                   as R0 sub-blocks of 256 points;
+//   middle          every sub-block is an independent 256-point transform  x multipliers x  inverse transform.  A
+//                   16-lane DPP row holds one sub-block, 16 points per lane: radix-16 butterfly in registers, twiddle,
+//                   lane <-> register transpose by DPP row operations (v_cndmask_b32 with row_shr / row_shl / quad_perm
+//                   modifiers), radix-16 butterfly, pointwise multiply (Source.cpp:414-427, the Nyquist-slot rule is
+//                   one table entry), and the same backwards.  No LDS traffic and no barrier inside: the waves of a
+//                   workgroup drift apart, so one wave's LDS reads and writes hide behind the others' arithmetic;
+//   inverse pass 0  conjugate twiddles, inverse radix-R0 butterflies, crop.
+// pffft's in-register SIMD passes (Source.cpp:531-533,553-555) become in-register wavefront passes.
+//
+// The engine's transform length N need not be the reference's: in the cropped region a circular convolution of any
+// length >= cols + 2 pad equals the linear convolution of the reflect-101 padded tile (Source.cpp:525-536), and the
+// one place where the reference's length shows -- the Nyquist bin scaled with the DC gain, Source.cpp:420-425 -- is an
+// additive term (K[0] - K[N/2]) / N_ref * (-1)^n * sum_m x[m] (-1)^m that is reproduced exactly by the multiplier of
+// bin N/2 (host_math.cpp: wr_multipliers).  So N is the next multiple of 256 with a supported R0.
+//
+// Pass order: COLUMNS FIRST, then rows.  The two 1D passes act on different axes and commute; with the column pass
+// first the awkward 3-byte pixels are only ever READ in 24-byte pieces (strip of 8 columns; over-fetch is absorbed by
+// L2), the float intermediate is written as whole 64-byte sectors into per-strip contiguous blocks, and the u8 result
+// leaves the row pass as whole image rows (16-byte stores).  Every HBM write is a full sector.
+//
+// Intermediate (per frame, per channel): [strip of 8 columns][row pair t][column 0..7][slot 0..1] floats; row r sits
+// in pair t = ((r + pad) >> 1) - (pad >> 1), slot (r + pad) & 1: pairs are aligned to the PADDED row index, so that
+// the two rows of a pair are neighbouring lanes (even, odd) of the column pass's last butterfly and one DPP quad_perm
+// puts them side by side.  The row pass takes pair t as its complex line: re = slot 0, im = slot 1.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fft_engine.hpp"
+
+namespace blur_amd {
+
+constexpr int kWrS = 256;          // points of a wave-resident sub-transform: 16 lanes x 16 registers
+constexpr int kWrSB = kWrS + 8;    // LDS stride of a sub-block (complex elements): the spare 64 bytes put the four
+                                   // sub-blocks a wave works on (lane & 3) on disjoint banks when it reads them
+
+// ---- lane <-> register transpose ---------------------------------------------------------------------------
+// The 16 lanes that hold one sub-block are the lanes of a wave with equal (lane & 3): lane bits 2..5 number them
+// (lambda = (lane >> 2) & 15), one lane out of every quad.  Register bit S is exchanged with lambda bit S:
+//   a = v[r] (bit S of r clear), b = v[r | 1 << S]:   a'[l] = hi(l) ? b[partner(l)] : a[l],   b'[l] = hi(l) ? b[l] : a[partner(l)]
+// with hi(l) = lambda bit S of lane l and partner(l) = the lane whose lambda differs in bit S.
+//   lambda bit 0 = lane bit 2: DPP row_shr:4 / row_shl:4, the select is the DPP bank mask (a bank = 4 lanes)
+//   lambda bit 1 = lane bit 3: DPP row_shr:8 / row_shl:8, bank mask
+//   lambda bit 2 = lane bit 4: v_permlane16_swap_b32 (odd rows of a <-> even rows of b, one instruction)
+//   lambda bit 3 = lane bit 5: v_permlane32_swap_b32 (upper half of a <-> lower half of b)
+// x of another lane of the same 16-lane DPP row (dpp_ctrl: quad_perm 0x00-0xFF, row_shl:n 0x100+n, row_shr:n 0x110+n)
+template <int CTRL> __device__ __forceinline__ float wr_dpp(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xf, 0xf, true));
+}
+
+template <int S> __device__ __forceinline__ void wr_xchg(float& a, float& b)
+{
+    const int ia = __builtin_bit_cast(int, a), ib = __builtin_bit_cast(int, b);
+    if constexpr (S == 0) {
+        const int na = __builtin_amdgcn_update_dpp(ia, ib, 0x114, 0xf, 0xA, false);   // row_shr:4 into banks 1,3
+        const int nb = __builtin_amdgcn_update_dpp(ib, ia, 0x104, 0xf, 0x5, false);   // row_shl:4 into banks 0,2
+        a = __builtin_bit_cast(float, na);
+        b = __builtin_bit_cast(float, nb);
+    } else if constexpr (S == 1) {
+        const int na = __builtin_amdgcn_update_dpp(ia, ib, 0x118, 0xf, 0xC, false);   // row_shr:8 into banks 2,3
+        const int nb = __builtin_amdgcn_update_dpp(ib, ia, 0x108, 0xf, 0x3, false);   // row_shl:8 into banks 0,1
+        a = __builtin_bit_cast(float, na);
+        b = __builtin_bit_cast(float, nb);
+    } else {
+        static_assert(S == 0 || S == 1, "lambda bits 2 and 3: wr_swap4");
+    }
+}
+
+// lambda bits 2 and 3: four register pairs per asm statement.  (The builtins __builtin_amdgcn_permlane16_swap /
+// permlane32_swap return both new values, but ROCm 7.2's optimiser folds the second result into the first.)
+// A VALU write of a register needs two wait states before a permlane swap reads it: the leading s_nop covers whatever
+// precedes the statement; the four swaps touch different registers; a VALU read right after a swap is safe.
+template <int S> __device__ __forceinline__ void wr_swap4(float& a0, float& b0, float& a1, float& b1, float& a2, float& b2, float& a3, float& b3)
+{
+    if constexpr (S == 2)
+        asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\tv_permlane16_swap_b32 %4, %5\n\tv_permlane16_swap_b32 %6, %7"
+            : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3));
+    else
+        asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\tv_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7"
+            : "+v"(a0), "+v"(b0), "+v"(a1), "+v"(b1), "+v"(a2), "+v"(b2), "+v"(a3), "+v"(b3));
+}
+
+template <int S> __device__ __forceinline__ void wr_xchg_step(float2 (&v)[16])
+{
+    constexpr int D = 1 << S;
+    if constexpr (S < 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if ((r & D) == 0) {
+                wr_xchg<S>(v[r].x, v[r | D].x);
+                wr_xchg<S>(v[r].y, v[r | D].y);
+            }
+        }
+    } else {
+        // the eight registers with bit S clear are {0..3} + {0, O}: O = 8 for S = 2, 4 for S = 3; four at a time
+        constexpr int O = S == 2 ? 8 : 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int b = h * O;
+            wr_swap4<S>(v[b].x, v[b | D].x, v[b + 1].x, v[(b + 1) | D].x, v[b + 2].x, v[(b + 2) | D].x, v[b + 3].x, v[(b + 3) | D].x);
+            wr_swap4<S>(v[b].y, v[b | D].y, v[b + 1].y, v[(b + 1) | D].y, v[b + 2].y, v[(b + 2) | D].y, v[b + 3].y, v[(b + 3) | D].y);
+        }
+    }
+}
+
+// v[r] of lane lambda  <->  v[lambda] of lane r, among the 16 lanes of a sub-block (tools/wr_model.py: transpose16)
+__device__ __forceinline__ void wr_transpose16(float2 (&v)[16])
+{
+    wr_xchg_step<0>(v);
+    wr_xchg_step<1>(v);
+    wr_xchg_step<2>(v);
+    wr_xchg_step<3>(v);
+}
+
+// per-thread constants of the middle section: tw[k] = exp(-2 pi i (lane & 15) k / 256), mm[rho] = multiplier of
+// frequency q + R0 (lane16 + 16 rho) of the line (natural order table)
+// TWL = false: tw in registers (30 VGPRs); true: read where used from a 2 KB LDS table [k][lambda] (the row pass, whose
+// register budget goes to the prefetched next unit)
+template <bool TWL> struct WrMid {
+    float2 tw[TWL ? 1 : 16];
+    const float2* twl;      // TWL: LDS table, entry k * 16 + lambda = exp(-2 pi i lambda k / 256)
+    float mm[16];
+    __device__ __forceinline__ float2 w(int k, int lane16) const
+    {
+        if constexpr (TWL) return twl[k * 16 + lane16];
+        else return tw[k];
+    }
+};
+constexpr size_t kWrTwlBytes = 16 * 16 * sizeof(float2);
+
+// fills the LDS twiddle table of the TWL variant (all threads; a barrier must follow)
+__device__ __forceinline__ void wr_twl_fill(float2* twl, const float2* __restrict__ w256, int tid, int nthreads)
+{
+    for (int i = tid; i < 256; i += nthreads) twl[i] = w256[((i >> 4) * (i & 15)) & 255];
+}
+
+template <int R0, bool TWL> __device__ __forceinline__ void wr_mid_load(WrMid<TWL>& w, int lane16, int q, const float2* __restrict__ w256, const float* __restrict__ mult, const float2* twl = nullptr)
+{
+    if constexpr (!TWL) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) w.tw[k] = w256[(lane16 * k) & 255];
+        w.tw[0] = make_float2(1.f, 0.f);
+    }
+    w.twl = twl;
+#pragma unroll
+    for (int rho = 0; rho < 16; ++rho) w.mm[rho] = mult[q + R0 * (lane16 + 16 * rho)];
+}
+
+// forward 256-point transform, pointwise multiply, inverse transform of the sub-block at `sb` (LDS), in place.
+// Lane lambda (= lane16) of the sub-block's 16 lanes holds elements lambda + 16 k.
+template <bool TWL> __device__ __forceinline__ void wr_middle(float2* sb, const WrMid<TWL>& w, int lane16)
+{
+    float2 v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = sb[16 * k + lane16];
+    Bfly<16, false>::run(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], w.w(k, lane16));
+    wr_transpose16(v);
+    Bfly<16, false>::run(v);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = cscale(v[r], w.mm[r]);
+    Bfly<16, true>::run(v);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) v[r] = cmulc(v[r], w.w(r, lane16));
+    wr_transpose16(v);
+    Bfly<16, true>::run(v);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sb[16 * k + lane16] = v[k];
+}
+
+// reflect-101 source index of padded position p (Source.cpp:525-529); -1: beyond the padded tile (zero)
+__device__ __forceinline__ int wr_reflect(int p, int pad, int len)
+{
+    int i = p - pad;
+    i = i < 0 ? -i : i;
+    const int m = 2 * (len - 1) - i;
+    const int r = i < len ? i : m;
+    return p < len + 2 * pad ? r : -1;
+}
+
+// pass 0, second half: butterfly, twiddle w_N^(j q), store element j of sub-block q
+template <int R0> __device__ __forceinline__ void wr_p0_store(float2 (&v)[R0], float2* line, const float2* tw0, int j)
+{
+    Bfly<R0, false>::run(v);
+    line[j] = v[0];
+#pragma unroll
+    for (int q = 1; q < R0; ++q) line[q * kWrSB + j] = cmul(v[q], tw0[(q - 1) * kWrS + j]);
+}
+// inverse pass 0, first half: load, conjugate twiddle, inverse butterfly: v[k] = element j + 256 k of the convolved line
+template <int R0> __device__ __forceinline__ void wr_ip0_load(float2 (&v)[R0], const float2* line, const float2* tw0, int j)
+{
+    v[0] = line[j];
+#pragma unroll
+    for (int q = 1; q < R0; ++q) v[q] = cmulc(line[q * kWrSB + j], tw0[(q - 1) * kWrS + j]);
+    Bfly<R0, true>::run(v);
+}
+
+// persistent workgroups, XCD-aware: workgroups b, b + 8, ... share an XCD (round-robin dispatch: speed only).  Each XCD
+// gets one contiguous run of units and its workgroups walk it interleaved, so that units whose data share 128-byte
+// lines are in flight together and meet in that XCD's L2.
+struct WrWalk {
+    int begin, end, step;
+};
+__device__ __forceinline__ WrWalk wr_walk(int nunits)
+{
+    const int nx = gridDim.x < 8 ? static_cast<int>(gridDim.x) : 8;
+    const int xcd = blockIdx.x % nx, rank = blockIdx.x / nx;
+    const int wg_in_xcd = (static_cast<int>(gridDim.x) - xcd + nx - 1) / nx;
+    const int b = static_cast<int>(static_cast<long long>(xcd) * nunits / nx);
+    const int e = static_cast<int>(static_cast<long long>(xcd + 1) * nunits / nx);
+    return WrWalk{ b + rank, e, wg_in_xcd };
+}
+
+template <int R0, int C> __host__ __device__ constexpr size_t wr_lines_bytes() { return static_cast<size_t>(C) * R0 * kWrSB * sizeof(float2); }
+template <int R0> __host__ __device__ constexpr size_t wr_tw0_bytes() { return static_cast<size_t>(R0 - 1) * kWrS * sizeof(float2); }
+
+// ======================================================================================
+// column pass (first): u8 pixels -> float intermediate
+// ======================================================================================
+// One workgroup per CU, persistent over (frame, strip of 2C = 8 columns).  The strip's raw bytes (24 per image row)
+// arrive by 8-byte loads issued into registers one strip ahead, are parked in an LDS byte stage and serve the three
+// channels one after the other (deinterleave_BGR, Utils.hpp:159-184, is the byte pick).  Per channel: pass 0 over the
+// C complex lines (line l = columns 2l, 2l+1; reflect-101 along the column, Source.cpp:549-551), middle, inverse pass 0,
+// and the cropped rows (Source.cpp:558) leave as 8-byte stores: the even lane of a lane pair holds row p, the odd lane
+// row p + 1 of the same two columns; one quad_perm exchange gives each lane one column with both rows.
+template <int R0, int C> __host__ __device__ constexpr size_t wr_col_lds(int rows)
+{
+    return wr_lines_bytes<R0, C>() + wr_tw0_bytes<R0>() + ((static_cast<size_t>(rows) + 1) * (2 * C * 3) + 15) / 16 * 16;
+}
+
+// ELO / EHI: the first ELO and the last EHI rounds k of pass 0 may touch the reflected borders or the zero tail (run-time
+// index arithmetic per element); the rounds between are interior for every thread (checked by the launcher).
+template <int R0, int C, int T, int ELO, int EHI>
+__global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ src, float* __restrict__ inter,
+                                                   int rows, int cols, int pad, int npairs, int nstrips, int nunits, int aligned8,
+                                                   const float2* __restrict__ w256, const float2* __restrict__ tw0g, const float* __restrict__ mult)
+{
+    constexpr int CH = 3, G = 2 * C, RB = G * CH;
+    constexpr int NSB = C * R0;                       // sub-blocks per task
+    static_assert(NSB * 16 <= T && T % 64 == 0, "the middle section is one round");
+    static_assert(RB % 8 == 0, "a strip row is a whole number of 8-byte pieces");
+    constexpr int total0 = C * kWrS, IT0 = (total0 + T - 1) / T;
+    constexpr int N = R0 * kWrS;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* lines = reinterpret_cast<float2*>(smem);
+    float2* tw0 = lines + C * R0 * kWrSB;
+    uint8_t* stage = reinterpret_cast<uint8_t*>(tw0 + (R0 - 1) * kWrS);      // [rows + 1][RB]; row `rows` stays zero
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (R0 - 1) * kWrS; i += T) tw0[i] = tw0g[i];
+    for (int i = tid; i < RB; i += T) stage[rows * RB + i] = 0;
+    const int lane16 = (tid >> 2) & 15, sbi = (tid >> 6) * 4 + (tid & 3);   // wr_transpose16's lane numbering
+    const bool mid_on = sbi < NSB;
+    WrMid<false> wm;
+    wr_mid_load<R0>(wm, lane16, mid_on ? sbi % R0 : 0, w256, mult);
+
+    // raw strip rows, one strip ahead, in registers: rows*3 pieces of 8 bytes
+    constexpr int PIECES = RB / 8;
+    constexpr int KU = (PIECES * N + T - 1) / T;      // rows < N
+    typedef unsigned int wr_u32x2 __attribute__((ext_vector_type(2)));
+    wr_u32x2 pfu[KU];
+    const size_t frame_bytes = static_cast<size_t>(rows) * cols * CH;
+    const int npiece = rows * PIECES;
+    auto strip_fast = [&](int uu) { const int ss = uu % nstrips; return aligned8 != 0 && (ss + 1) * G <= cols; };
+    auto issue_strip = [&](int uu) {
+        if (!strip_fast(uu)) return;
+        const int ff = uu / nstrips, ss = uu - ff * nstrips;
+        const uint8_t* base = src + static_cast<size_t>(ff) * frame_bytes + static_cast<size_t>(ss) * RB;
+        int t0 = tid;
+        asm volatile("" : "+v"(t0));
+#pragma unroll
+        for (int k = 0; k < KU; ++k) {
+            int idx = t0 + T * k;
+            idx = idx < npiece ? idx : npiece - 1;              // unconditional loads: all in flight together
+            const int r = idx / PIECES, d = idx - r * PIECES;
+            pfu[k] = *reinterpret_cast<const wr_u32x2*>(base + static_cast<size_t>(r) * cols * CH + 8 * d);
+        }
+    };
+    auto claim_strip = [&]() {
+#pragma unroll
+        for (int k = 0; k < KU; ++k) asm volatile("" ::"v"(pfu[k].x), "v"(pfu[k].y));
+    };
+    auto commit_strip = [&](int uu) {
+        if (strip_fast(uu)) {
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                const int idx = tid + T * k;
+                if (idx < npiece) reinterpret_cast<wr_u32x2*>(stage)[idx] = pfu[k];
+            }
+        } else {
+            // ragged last strip or rows that are not 8-byte aligned: byte loads, columns beyond the image are zero
+            const int ff = uu / nstrips, ss = uu - ff * nstrips;
+            const uint8_t* base = src + static_cast<size_t>(ff) * frame_bytes;
+            for (int idx = tid; idx < rows * RB; idx += T) {
+                const int r = idx / RB, b = idx - r * RB;
+                const int col = ss * G + b / CH;
+                stage[idx] = col < cols ? base[(static_cast<size_t>(r) * cols + col) * CH + (b % CH)] : static_cast<uint8_t>(0);
+            }
+        }
+    };
+
+    const WrWalk walk = wr_walk(nunits);
+    if (walk.begin < walk.end) {
+        issue_strip(walk.begin);
+        claim_strip();
+        commit_strip(walk.begin);
+        if (walk.begin + walk.step < walk.end) issue_strip(walk.begin + walk.step);
+        claim_strip();
+    }
+    __syncthreads();
+    const size_t plane = static_cast<size_t>(nstrips) * npairs * (2 * G);     // floats per channel
+    for (int u = walk.begin; u < walk.end; u += walk.step) {
+        const int f = u / nstrips, strip = u - f * nstrips;
+        for (int ch = 0; ch < CH; ++ch) {
+            // ---- pass 0: bytes -> butterfly -> twiddle -> LDS
+#pragma unroll
+            for (int it = 0; it < IT0; ++it) {
+                int g = tid + T * it;
+                asm volatile("" : "+v"(g));
+                if (IT0 * T == total0 || g < total0) {
+                    const int l = g >> 8, j = g & 255;
+                    float2 v[R0];
+                    const uint8_t* sl = stage + (2 * l) * CH + ch;
+#pragma unroll
+                    for (int k = 0; k < R0; ++k) {
+                        int r;
+                        if (k >= ELO && k < R0 - EHI) r = j + k * kWrS - pad;      // the whole round is interior
+                        else { r = wr_reflect(j + k * kWrS, pad, rows); r = r < 0 ? rows : r; }
+                        const uint8_t* s = sl + r * RB;
+                        v[k] = make_float2(static_cast<float>(s[0]), static_cast<float>(s[CH]));
+                    }
+                    wr_p0_store<R0>(v, lines + l * (R0 * kWrSB), tw0, j);
+                }
+            }
+            __syncthreads();
+            if (ch == CH - 1) {
+                // every byte of this strip has been read: park the next strip, request the one after
+                const int un = u + walk.step;
+                if (un < walk.end) {
+                    commit_strip(un);
+                    if (un + walk.step < walk.end) issue_strip(un + walk.step);
+                }
+            }
+            // ---- middle: wave-resident, no barrier inside
+            if (mid_on) wr_middle(lines + sbi * kWrSB, wm, lane16);
+            __syncthreads();
+            if (ch == CH - 1) claim_strip();      // before this task's stores (vmcnt retires in order)
+            // ---- inverse pass 0 -> cropped rows, pair-interleaved, strip-tiled
+            float* const out_plane = inter + (static_cast<size_t>(f) * CH + ch) * plane + static_cast<size_t>(strip) * npairs * (2 * G);
+#pragma unroll
+            for (int it = 0; it < IT0; ++it) {
+                int g = tid + T * it;
+                asm volatile("" : "+v"(g));
+                if (IT0 * T == total0 || g < total0) {
+                    const int l = g >> 8, j = g & 255;
+                    float2 v[R0];
+                    wr_ip0_load<R0>(v, lines + l * (R0 * kWrSB), tw0, j);
+                    const bool odd = (j & 1) != 0;
+                    const int col2 = 2 * (2 * l + (odd ? 1 : 0));            // float offset of this lane's column inside a pair record
+#pragma unroll
+                    for (int k = 0; k < R0; ++k) {
+                        // even lane: row p (slot 0) of columns 2l, 2l+1; odd lane: row p + 1 (slot 1) of the same columns
+                        const float px = wr_dpp<0xB1>(v[k].x), py = wr_dpp<0xB1>(v[k].y);
+                        const float2 o = odd ? make_float2(py, v[k].y) : make_float2(v[k].x, px);
+                        const int t = ((j + k * kWrS) >> 1) - (pad >> 1);
+                        if (t >= 0 && t < npairs) *reinterpret_cast<float2*>(out_plane + t * (2 * G) + col2) = o;
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ======================================================================================
+// row pass (second): float intermediate -> u8 pixels
+// ======================================================================================
+// One workgroup of 3 * 256 threads per CU, persistent over (frame, row pair); the three channel lines of the pair are
+// transformed together.  Pass 0 takes its input straight from global memory: thread (c, j) owns columns
+// reflect(j + 256 k - pad) (Source.cpp:525-529), one 8-byte load each (slot 0, slot 1 = re, im), requested one unit
+// ahead into registers.  The last butterfly applies interleave_BGR's "+0.5f, truncate" (Utils.hpp:189,204-206) into an
+// LDS byte stage that leaves as two whole image rows.
+template <int R0> __host__ __device__ constexpr size_t wr_row_lds(int cols)
+{
+    return wr_lines_bytes<R0, 3>() + wr_tw0_bytes<R0>() + kWrTwlBytes + 2 * ((static_cast<size_t>(cols) * 3 + 15) / 16 * 16);
+}
+
+template <int R0, int T, int ELO, int EHI>
+__global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ inter, uint8_t* __restrict__ dst,
+                                                   int rows, int cols, int pad, int npairs, int nstrips, int nunits, int aligned16,
+                                                   const float2* __restrict__ w256, const float2* __restrict__ tw0g, const float* __restrict__ mult)
+{
+    constexpr int CH = 3, C = 3, G = 8;
+    constexpr int NSB = C * R0;
+    static_assert(T == C * kWrS, "pass 0: one butterfly per thread");
+    static_assert(NSB * 16 <= T, "the middle section is one round");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* lines = reinterpret_cast<float2*>(smem);
+    float2* tw0 = lines + C * R0 * kWrSB;
+    float2* twl = tw0 + (R0 - 1) * kWrS;
+    uint8_t* stage = reinterpret_cast<uint8_t*>(twl + 256);
+    const int rowbytes = cols * CH;
+    const int stage_row = (rowbytes + 15) / 16 * 16;
+
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (R0 - 1) * kWrS; i += T) tw0[i] = tw0g[i];
+    wr_twl_fill(twl, w256, tid, T);
+    const int lane16 = (tid >> 2) & 15, sbi = (tid >> 6) * 4 + (tid & 3);   // wr_transpose16's lane numbering
+    const bool mid_on = sbi < NSB;
+    WrMid<true> wm;
+    wr_mid_load<R0>(wm, lane16, mid_on ? sbi % R0 : 0, w256, mult, twl);
+
+    const int c = tid >> 8;
+    const size_t plane = static_cast<size_t>(nstrips) * npairs * (2 * G);
+    const int strip_step = npairs * (2 * G);                     // floats between the same pair of neighbouring strips
+    // the thread's butterfly index, opaque to the optimiser: otherwise every per-thread offset that follows from it is
+    // hoisted out of the unit loop and held in registers for the whole kernel (fast_kernels.hpp: 168 -> 102 VGPRs)
+    auto my_j = [&]() -> int { int t_ = tid; asm volatile("" : "+v"(t_)); return t_ & 255; };
+    // column index of padded position j + 256 k: -1 = zero
+    auto col_of = [&](int j, int k) -> int {
+        if (k >= ELO && k < R0 - EHI) return j + k * kWrS - pad;     // interior round (launcher)
+        return wr_reflect(j + k * kWrS, pad, cols);
+    };
+    typedef float wr_f32x2 __attribute__((ext_vector_type(2)));
+    wr_f32x2 pf[R0];
+    auto issue_unit = [&](int uu) {
+        const int ff = uu / npairs, tt = uu - ff * npairs;
+        const float* base = inter + (static_cast<size_t>(ff) * CH + c) * plane + static_cast<size_t>(tt) * (2 * G);
+        const int j = my_j();
+#pragma unroll
+        for (int k = 0; k < R0; ++k) {
+            int x = col_of(j, k);
+            x = x < 0 ? 0 : x;                                   // unconditional loads, masked at use
+            pf[k] = *reinterpret_cast<const wr_f32x2*>(base + static_cast<size_t>(x >> 3) * strip_step + 2 * (x & 7));
+        }
+    };
+    auto claim_unit = [&]() {
+#pragma unroll
+        for (int k = 0; k < R0; ++k) asm volatile("" ::"v"(pf[k].x), "v"(pf[k].y));
+    };
+
+    const WrWalk walk = wr_walk(nunits);
+    if (walk.begin < walk.end) issue_unit(walk.begin);
+    claim_unit();
+    __syncthreads();
+    for (int u = walk.begin; u < walk.end; u += walk.step) {
+        const int f = u / npairs, t = u - f * npairs;
+        const int r0 = 2 * t - (pad & 1);                        // slot 0 row (may be -1), slot 1 row r0 + 1 (may be rows)
+        // ---- pass 0
+        {
+            float2 v[R0];
+            const int j = my_j();
+#pragma unroll
+            for (int k = 0; k < R0; ++k) v[k] = col_of(j, k) >= 0 ? make_float2(pf[k].x, pf[k].y) : make_float2(0.f, 0.f);
+            if (u + walk.step < walk.end) issue_unit(u + walk.step);          // in flight across the whole unit
+            wr_p0_store<R0>(v, lines + c * (R0 * kWrSB), tw0, j);
+        }
+        __syncthreads();
+        if (mid_on) wr_middle(lines + sbi * kWrSB, wm, lane16);
+        __syncthreads();
+        // ---- inverse pass 0 -> "+0.5f, truncate" -> byte stage
+        {
+            float2 v[R0];
+            const int j = my_j();
+            wr_ip0_load<R0>(v, lines + c * (R0 * kWrSB), tw0, j);
+#pragma unroll
+            for (int k = 0; k < R0; ++k) {
+                const int x = j + k * kWrS - pad;
+                if ((k >= ELO && k < R0 - EHI) || (x >= 0 && x < cols)) {
+                    uint8_t* s = stage + x * CH + c;
+                    s[0] = static_cast<uint8_t>(static_cast<int>(v[k].x + 0.5f));
+                    s[stage_row] = static_cast<uint8_t>(static_cast<int>(v[k].y + 0.5f));
+                }
+            }
+        }
+        claim_unit();                 // before this unit's stores (vmcnt retires in order)
+        __syncthreads();
+        // ---- two whole image rows out
+        uint8_t* const out0 = dst + (static_cast<size_t>(f) * rows + (r0 < 0 ? 0 : r0)) * rowbytes;
+        const bool ok0 = r0 >= 0, ok1 = r0 + 1 < rows;
+        if (aligned16) {
+            const int nchunk = rowbytes >> 4;
+            for (int idx = tid; idx < 2 * nchunk; idx += T) {
+                const int rb = idx >= nchunk ? 1 : 0, i = idx - rb * nchunk;
+                if (rb ? ok1 : ok0)
+                    *reinterpret_cast<uint4*>(out0 + static_cast<size_t>(rb && ok0 ? rowbytes : 0) + 16 * i) =
+                        *reinterpret_cast<const uint4*>(stage + rb * stage_row + 16 * i);
+            }
+        } else {
+            for (int idx = tid; idx < 2 * rowbytes; idx += T) {
+                const int rb = idx >= rowbytes ? 1 : 0, i = idx - rb * rowbytes;
+                if (rb ? ok1 : ok0) out0[static_cast<size_t>(rb && ok0 ? rowbytes : 0) + i] = stage[rb * stage_row + i];
+            }
+        }
+        // the next unit's pass 0 writes `lines` (free: every thread has passed the barrier above) and its inverse pass 0
+        // writes the stage only after two more barriers
+    }
+}
+
+// ======================================================================================
+// complex lines in, convolved complex lines out (tests, and the batched line API)
+// ======================================================================================
+template <int R0, int C, int T>
+__global__ __launch_bounds__(T) void wr_lines_kernel(const float2* __restrict__ in, float2* __restrict__ out, int nlines,
+                                                     const float2* __restrict__ w256, const float2* __restrict__ tw0g, const float* __restrict__ mult)
+{
+    constexpr int NSB = C * R0, N = R0 * kWrS;
+    constexpr int total0 = C * kWrS, IT0 = (total0 + T - 1) / T;
+    static_assert(NSB * 16 <= T && T % 64 == 0, "the middle section is one round");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float2* lines = reinterpret_cast<float2*>(smem);
+    float2* tw0 = lines + C * R0 * kWrSB;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (R0 - 1) * kWrS; i += T) tw0[i] = tw0g[i];
+    const int lane16 = (tid >> 2) & 15, sbi = (tid >> 6) * 4 + (tid & 3);   // wr_transpose16's lane numbering
+    const bool mid_on = sbi < NSB;
+    WrMid<false> wm;
+    wr_mid_load<R0>(wm, lane16, mid_on ? sbi % R0 : 0, w256, mult);
+    __syncthreads();
+    for (int l0 = blockIdx.x * C; l0 < nlines; l0 += gridDim.x * C) {
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int g = tid + T * it;
+            if (g < total0) {
+                const int l = g >> 8, j = g & 255;
+                float2 v[R0];
+                const int line = l0 + l < nlines ? l0 + l : nlines - 1;
+#pragma unroll
+                for (int k = 0; k < R0; ++k) v[k] = in[static_cast<size_t>(line) * N + j + k * kWrS];
+                wr_p0_store<R0>(v, lines + l * (R0 * kWrSB), tw0, j);
+            }
+        }
+        __syncthreads();
+        if (mid_on) wr_middle(lines + sbi * kWrSB, wm, lane16);
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int g = tid + T * it;
+            if (g < total0) {
+                const int l = g >> 8, j = g & 255;
+                float2 v[R0];
+                wr_ip0_load<R0>(v, lines + l * (R0 * kWrSB), tw0, j);
+                if (l0 + l < nlines) {
+#pragma unroll
+                    for (int k = 0; k < R0; ++k) out[static_cast<size_t>(l0 + l) * N + j + k * kWrS] = v[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---- launchers ---------------------------------------------------------------------------
+struct WrEntry {
+    int r0;          // N = 256 * r0
+    int threads;
+    // columns first: u8 frames -> intermediate
+    hipError_t (*col_u8)(hipStream_t, const uint8_t* src, float* inter, int rows, int cols, int pad, int nframes, int num_cus,
+                         const float2* w256, const float2* tw0, const float* mult);
+    size_t (*col_lds)(int rows);
+    // rows second: intermediate -> u8 frames
+    hipError_t (*row_u8)(hipStream_t, const float* inter, uint8_t* dst, int rows, int cols, int pad, int nframes, int num_cus,
+                         const float2* w256, const float2* tw0, const float* mult);
+    size_t (*row_lds)(int cols);
+    // complex lines of length N (in == out allowed)
+    hipError_t (*lines)(hipStream_t, const float2* in, float2* out, int nlines, int num_cus, const float2* w256, const float2* tw0, const float* mult);
+};
+
+inline int wr_npairs(int rows, int pad) { return ((rows - 1 + pad) >> 1) - (pad >> 1) + 1; }
+inline size_t wr_frame_floats(int rows, int cols, int pad) { return static_cast<size_t>((cols + 7) / 8) * wr_npairs(rows, pad) * 16 * 3; }
+
+inline int wr_balanced_grid(int units, int slots)
+{
+    if (units <= slots) return units;
+    const int rounds = (units + slots - 1) / slots;
+    return (units + rounds - 1) / rounds;
+}
+
+template <class K> hipError_t wr_set_lds(K kern, size_t lds)
+{
+    if (lds > 64 * 1024) return hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    return hipSuccess;
+}
+
+template <int R0, int C, int T>
+hipError_t wr_launch_col_u8(hipStream_t st, const uint8_t* src, float* inter, int rows, int cols, int pad, int nframes, int num_cus,
+                            const float2* w256, const float2* tw0, const float* mult)
+{
+    if (rows + 2 * pad > R0 * kWrS || pad > rows - 1) return hipErrorInvalidValue;
+    const size_t lds = wr_col_lds<R0, C>(rows);
+    // rounds k with 256 k >= pad and 256 (k + 1) <= pad + rows are interior
+    const int elo = (pad + kWrS - 1) / kWrS, ehi = R0 - (pad + rows) / kWrS;
+    auto kern = (elo <= 1 && ehi <= 1) ? wr_colpass_u8<R0, C, T, 1, 1> : wr_colpass_u8<R0, C, T, R0, 0>;
+    if (hipError_t e = wr_set_lds(kern, lds); e != hipSuccess) return e;
+    const int nstrips = (cols + 2 * C - 1) / (2 * C), npairs = wr_npairs(rows, pad), nunits = nstrips * nframes;
+    // 32-bit float offsets inside a channel plane
+    if (static_cast<size_t>(nstrips) * npairs * 4 * C >= (static_cast<size_t>(1) << 30)) return hipErrorInvalidValue;
+    const int aligned8 = ((reinterpret_cast<uintptr_t>(src) & 7) == 0 && ((static_cast<size_t>(cols) * 3) & 7) == 0) ? 1 : 0;
+    const int grid = wr_balanced_grid(nunits, num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, src, inter, rows, cols, pad, npairs, nstrips, nunits, aligned8, w256, tw0, mult);
+    return hipGetLastError();
+}
+
+template <int R0, int T>
+hipError_t wr_launch_row_u8(hipStream_t st, const float* inter, uint8_t* dst, int rows, int cols, int pad, int nframes, int num_cus,
+                            const float2* w256, const float2* tw0, const float* mult)
+{
+    if (cols + 2 * pad > R0 * kWrS || pad > cols - 1) return hipErrorInvalidValue;
+    const size_t lds = wr_row_lds<R0>(cols);
+    const int elo = (pad + kWrS - 1) / kWrS, ehi = R0 - (pad + cols) / kWrS;
+    auto kern = (elo <= 1 && ehi <= 1) ? wr_rowpass_u8<R0, T, 1, 1> : wr_rowpass_u8<R0, T, R0, 0>;
+    if (hipError_t e = wr_set_lds(kern, lds); e != hipSuccess) return e;
+    const int nstrips = (cols + 7) / 8, npairs = wr_npairs(rows, pad), nunits = npairs * nframes;
+    if (static_cast<size_t>(nstrips) * npairs * 16 >= (static_cast<size_t>(1) << 30)) return hipErrorInvalidValue;
+    const int aligned16 = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && ((static_cast<size_t>(cols) * 3) & 15) == 0) ? 1 : 0;
+    const int grid = wr_balanced_grid(nunits, num_cus);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, inter, dst, rows, cols, pad, npairs, nstrips, nunits, aligned16, w256, tw0, mult);
+    return hipGetLastError();
+}
+
+template <int R0, int C, int T>
+hipError_t wr_launch_lines(hipStream_t st, const float2* in, float2* out, int nlines, int num_cus, const float2* w256, const float2* tw0, const float* mult)
+{
+    const size_t lds = wr_lines_bytes<R0, C>() + wr_tw0_bytes<R0>();
+    auto kern = wr_lines_kernel<R0, C, T>;
+    if (hipError_t e = wr_set_lds(kern, lds); e != hipSuccess) return e;
+    const int units = (nlines + C - 1) / C;
+    if (units <= 0) return hipSuccess;
+    const int grid = units < num_cus ? units : num_cus;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, in, out, nlines, w256, tw0, mult);
+    return hipGetLastError();
+}
+
+
+}  // namespace blur_amd
+
+// one translation unit per (R0, role):  BLUR_WR_COL(9, 4, 576)   BLUR_WR_ROW(16, 768)
+#define BLUR_WR_COL(R0_, C_, T_)                                                                  \
+    namespace blur_amd {                                                                          \
+    const WrEntry* wr_col_entry_##R0_()                                                           \
+    {                                                                                             \
+        static const WrEntry e = { R0_, T_, wr_launch_col_u8<R0_, C_, T_>, wr_col_lds<R0_, C_>, nullptr, nullptr, \
+                                   wr_launch_lines<R0_, C_, T_> };                                \
+        return &e;                                                                                \
+    }                                                                                             \
+    }
+#define BLUR_WR_ROW(R0_, T_)                                                                      \
+    namespace blur_amd {                                                                          \
+    const WrEntry* wr_row_entry_##R0_()                                                           \
+    {                                                                                             \
+        static const WrEntry e = { R0_, T_, nullptr, nullptr, wr_launch_row_u8<R0_, T_>, wr_row_lds<R0_>, \
+                                   wr_launch_lines<R0_, 3, T_> };                                 \
+        return &e;                                                                                \
+    }                                                                                             \
+    }

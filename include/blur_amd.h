@@ -51,7 +51,9 @@ typedef struct blur_opts {
        one exists (tests); reserved[1] > 0: frames per launch pair of the batch entry point
        (0 = auto: as many as fit a 1 GiB float workspace);
        reserved[2] = 1: keep the float intermediate in row-major planes even when both passes are
-       specialised (default: strips of 8 columns stored contiguously) */
+       specialised (default: strips of 8 columns stored contiguously);
+       reserved[3] = 1: do not use the wave-resident kernels (transform length 256 * R0, columns first;
+       DESIGN.md) even where both passes have one (tests, A/B timing) */
     int reserved[6];
 } blur_opts;
 
@@ -177,6 +179,22 @@ int blur_fastboxblur_u8_dev(blur_ctx* ctx, uint8_t* d_inout, int w, int h, int c
                             int ksize, int passes);
 int blur_fastboxblur_u8_host(blur_ctx* ctx, uint8_t* inout, int w, int h, int channels,
                              int ksize, int passes);
+
+/* ---- batched line convolution: what pffft_transform_ordered(FORWARD) -> pffft_sorted_optimized_convolution ->
+   pffft_transform_ordered(BACKWARD) (Source.cpp:531-533,553-555) is per tile, for MANY lines at once --------------
+   d_in / d_out: nlines complex lines of n points each (interleaved re, im floats; in == out allowed),
+   out = IDFT_n(multipliers .* DFT_n(in)), UNNORMALISED like pffft (fold 1/n into the multipliers, Source.cpp:423);
+   multipliers: n real factors in natural frequency order (host pointer; cached on the device by content).
+   Two real lines ride in one complex line when the multipliers are even (m[f] = m[n-f]): re and im are then
+   convolved independently.  n must be a length the wave-resident kernels support: blur_wr_length(). */
+int blur_convolve_lines_c32_dev(blur_ctx* ctx, const float* d_in, float* d_out, int nlines, int n, const float* multipliers);
+/* smallest supported transform length >= need for the column (1) or row (0) role; 0 if there is none.
+   (The engine's transform length need not be nearestTransformSize(): only the Nyquist-slot term of Source.cpp:420-425
+   depends on the reference's length, and the multiplier of bin n/2 reproduces it.) */
+int blur_wr_length(int need, int column_role);
+/* the multipliers those kernels use for the Gaussian, all n bins in natural order: m[f] = Re DFT_n(kernel)[f] / n, and with
+   quirk != 0 bin n/2 carries the reference's Nyquist-slot term for ITS transform length n_ref (Source.cpp:420-425).  Host only. */
+int blur_wr_kernel_multipliers(double sigma, int ksize, int n, int n_ref, int quirk, float* m);
 
 /* ---- plain device-memory plumbing for callers without a HIP runtime of their own --- */
 int blur_malloc(blur_ctx* ctx, void** d_ptr, size_t bytes);

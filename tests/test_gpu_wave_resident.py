@@ -1,0 +1,136 @@
+"""GPU tests of the wave-resident kernels (csrc/wr_kernels.hpp): pass 0 through LDS, 256-point sub-transforms on
+16 lanes x 16 registers with DPP / permlane-swap transposes, columns first.  Against numpy's FFT for the line
+engine and against the float64 oracle of pffft_() (Source.cpp:429-570) for whole images."""
+import numpy as np
+import pytest
+
+from conftest import assert_u8_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _rand_img(rows, cols, seed):
+    return np.random.default_rng(seed).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("n", [2304, 4096])
+@pytest.mark.parametrize("nlines", [1, 4, 7, 1500])
+def test_convolve_lines_against_numpy(ctx, n, nlines):
+    """IDFT(m * DFT(x)) of complex lines: every butterfly, twiddle, transpose and the natural-order multiplier lookup"""
+    torch = _torch()
+    rng = np.random.default_rng(n + nlines)
+    x = (rng.standard_normal((nlines, n)) + 1j * rng.standard_normal((nlines, n))).astype(np.complex64)
+    m = rng.standard_normal(n).astype(np.float32)
+    got = ctx.convolve_lines(torch.from_numpy(x).cuda(), m).cpu().numpy()
+    want = np.fft.ifft(np.fft.fft(x.astype(np.complex128), axis=1) * m.astype(np.float64), axis=1) * n
+    scale = np.abs(want).max()
+    err = np.abs(got - want).max() / scale
+    assert err < 2e-6, err
+    # in place
+    t = torch.from_numpy(x).cuda()
+    ctx.convolve_lines(t, m, out=t)
+    assert np.array_equal(t.cpu().numpy(), got)
+
+
+def test_convolve_lines_impulse_positions(ctx):
+    """a unit impulse at every position class: catches any index mix-up that random data would only show as 'wrong'"""
+    torch = _torch()
+    for n in (2304, 4096):
+        pos = [0, 1, 15, 16, 17, 255, 256, 257, n // 2, n - 1, 1000]
+        x = np.zeros((len(pos), n), np.complex64)
+        for i, p in enumerate(pos):
+            x[i, p] = 1 + 2j
+        m = np.cos(2 * np.pi * 3 * np.arange(n) / n).astype(np.float32) + 2       # kernel 2 delta[0] + (delta[3] + delta[-3]) / 2
+        got = ctx.convolve_lines(torch.from_numpy(x).cuda(), m).cpu().numpy() / n
+        for i, p in enumerate(pos):
+            want = np.zeros(n, np.complex128)
+            want[p] += 2 * (1 + 2j)
+            want[(p + 3) % n] += 0.5 * (1 + 2j)
+            want[(p - 3) % n] += 0.5 * (1 + 2j)
+            assert np.abs(got[i] - want).max() < 1e-5, (n, p)
+
+
+# small and odd images forced through the wave-resident kernels (N = 2304 / 4096 whatever the image): ragged last strip,
+# single last row, unaligned rows (byte path), pad parity both ways, fewer units than CUs
+SMALL = [
+    (64, 96, 3.0),
+    (33, 47, 2.0),
+    (100, 77, 5.0),
+    (101, 203, 4.0),
+    (270, 480, 20.0),
+    (500, 748, 20.0),
+    (16, 16, 1.0),
+    (301, 8, 1.2),
+]
+
+
+@pytest.mark.parametrize("rows,cols,sigma", SMALL)
+@pytest.mark.parametrize("quirk", [True, False])
+def test_small_images_forced_wave_resident(ctx, rows, cols, sigma, quirk):
+    torch = _torch()
+    from oracle import oracle as O
+    img = _rand_img(rows, cols, 3)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    got = ctx.pffft_(t, sigma, out=torch.empty_like(t), nyquist_quirk=quirk, wave_resident=True)
+    assert_u8_parity(got.cpu().numpy(), want, planes)
+    # in place, like the reference
+    ctx.pffft_(t, sigma, nyquist_quirk=quirk, wave_resident=True)
+    assert torch.equal(t, got)
+
+
+# thin images whose long side is the metric's: the real transform lengths with the real pad, cheap for the oracle
+THIN = [
+    (2160, 70, 20.0),
+    (2159, 67, 20.0),
+    (70, 3840, 20.0),
+    (71, 3839, 20.0),
+    (2174, 66, 20.0),     # rows + 2 pad = 2304 exactly: no zero tail
+    (66, 3966, 20.0),     # cols + 2 pad = 4096 exactly
+]
+
+
+@pytest.mark.parametrize("rows,cols,sigma", THIN)
+def test_metric_lengths_forced_wave_resident(ctx, rows, cols, sigma):
+    torch = _torch()
+    from oracle import oracle as O
+    img = _rand_img(rows, cols, 4)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, True, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    got = ctx.pffft_(t, sigma, out=torch.empty_like(t), wave_resident=True)
+    assert_u8_parity(got.cpu().numpy(), want, planes)
+
+
+def test_batch_equals_single_frames_wave_resident(ctx):
+    torch = _torch()
+    frames = np.stack([_rand_img(120, 200, 40 + i) for i in range(5)])
+    t = torch.from_numpy(frames).cuda()
+    got = ctx.pffft_(t, 6.0, out=torch.empty_like(t), wave_resident=True)
+    for i in range(5):
+        one = ctx.pffft_(t[i].contiguous(), 6.0, out=torch.empty_like(t[i]), wave_resident=True)
+        assert torch.equal(got[i], one)
+    # frames per launch is a scheduling choice
+    again = ctx.pffft_(t, 6.0, out=torch.empty_like(t), wave_resident=True, frames_per_launch=2)
+    assert torch.equal(got, again)
+
+
+def test_wave_resident_is_the_default_on_the_metric_frame(ctx):
+    """4K sigma 20 takes the wave-resident kernels by default; switching them off gives the rows-first kernels.  Both
+    obey the parity contract; they differ from each other only at rounding ties."""
+    torch = _torch()
+    from oracle import oracle as O
+    img = _rand_img(2160, 3840, 99)
+    want, planes = O.pffft_blur_u8c3_f64(img, 20.0, True, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    a = ctx.pffft_(t, 20.0, out=torch.empty_like(t))
+    b = ctx.pffft_(t, 20.0, out=torch.empty_like(t), wave_resident=True)
+    assert torch.equal(a, b)
+    assert_u8_parity(a.cpu().numpy(), want, planes)
+    c = ctx.pffft_(t, 20.0, out=torch.empty_like(t), wave_resident=False)
+    assert_u8_parity(c.cpu().numpy(), want, planes)
+    assert (a != c).float().mean().item() < 1e-4

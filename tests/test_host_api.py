@@ -116,3 +116,42 @@ def test_cpp_header_with_reference_names():
                            "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     out = subprocess.run([exe, "host"], capture_output=True, text=True)
     assert out.returncode == 0 and "host ok" in out.stdout, out.stdout + out.stderr
+
+
+def _reflect_tile(x, pad, n):
+    """reflect-101 padded tile of Source.cpp:525-529, zero-extended to n"""
+    L = len(x)
+    t = np.zeros(n)
+    t[:pad] = x[pad:0:-1]
+    t[pad:pad + L] = x
+    t[pad + L:pad + L + pad] = x[L - 2:L - 2 - pad:-1]
+    return t
+
+
+@pytest.mark.parametrize("L,sigma", [(2160, 20.0), (3840, 20.0), (700, 7.0), (300, 2.0)])
+@pytest.mark.parametrize("quirk", [1, 0])
+def test_wr_multipliers_reproduce_the_reference_length(L, sigma, quirk):
+    """The wave-resident kernels transform at n = 256 * R0 instead of the reference's nearestTransformSize().  In the
+    cropped region the result must not change: the convolution part is length-independent and the Nyquist-slot term
+    of Source.cpp:420-425 (which does depend on the reference's length) is carried by the multiplier of bin n/2."""
+    from blur_algorithms_amd import _lib
+    lib = _lib.load()
+    ks = lib.blur_gaussian_window(sigma, L)
+    pad = (ks - 1) // 2
+    n_ref = lib.blur_nearest_transform_size(L + 2 * pad) if not lib.blur_is_valid_size(L + 2 * pad) else L + 2 * pad
+    x = np.random.default_rng(5).integers(0, 256, L).astype(np.float64)
+    # the reference's own arithmetic at its own length: bins 0..n/2, slot 1 (Nyquist) scaled with bin 0's factor
+    m = np.zeros(n_ref // 2 + 1, np.float32)
+    assert lib.blur_kernel_multipliers(sigma, ks, n_ref, m.ctypes.data) == 0
+    full = np.concatenate([m, m[-2:0:-1]]).astype(np.float64)
+    if quirk:
+        full[n_ref // 2] = m[0]
+    want = np.fft.ifft(np.fft.fft(_reflect_tile(x, pad, n_ref)) * full).real[pad:pad + L] * n_ref
+    for n in sorted({256 * r for r in (3, 4, 5, 9, 10, 16, 18, 20)}):
+        if n < L + 2 * pad:
+            continue
+        mm = np.zeros(n, np.float32)
+        assert lib.blur_wr_kernel_multipliers(sigma, ks, n, n_ref, quirk, mm.ctypes.data) == 0
+        assert np.array_equal(mm[1:], mm[:0:-1])            # even: two real lines may share a complex line
+        got = np.fft.ifft(np.fft.fft(_reflect_tile(x, pad, n)) * mm.astype(np.float64)).real[pad:pad + L] * n
+        assert np.abs(got - want).max() < 3e-5, (n, np.abs(got - want).max())    # float32 rounding of the two tables
