@@ -762,9 +762,12 @@ static int wr_get_spectrum(blur_ctx* ctx, const std::tuple<int, int, int, int, u
     std::vector<float> m(n);
     wr_multipliers(karr.data(), n, n_ref, quirk, m.data());
     float* d = nullptr;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(float) * n));
+    // the tail behind the table is only written by -DWR_STAMPS diagnostic builds
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), sizeof(float) * (n + kWrStampTailFloats)));
+    HIP_TRY(ctx, hipMemset(d, 0, sizeof(float) * (n + kWrStampTailFloats)));
     HIP_TRY(ctx, hipMemcpy(d, m.data(), sizeof(float) * n, hipMemcpyHostToDevice));
     ctx->wr_spectra[key] = d;
+    ctx->last_spectrum[-n] = d;
     *out = d;
     return BLUR_OK;
 }
@@ -1455,7 +1458,7 @@ int blur_wr_length(int need, int column_role)
 int blur_debug_read_stamps(blur_ctx* ctx, int n, int role, unsigned long long* out, int count)
 {
     if (!ctx || !out) return BLUR_ERR_INVALID;
-    auto it = ctx->last_spectrum.find(4 * n + role);
+    auto it = ctx->last_spectrum.find(role < 0 ? -n : 4 * n + role);      // role < 0: the wave-resident kernel of length n
     if (it == ctx->last_spectrum.end() || count * sizeof(unsigned long long) > kStampTailFloats * sizeof(float)) return BLUR_ERR_INVALID;
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     HIP_TRY(ctx, hipMemcpy(out, it->second + n, count * sizeof(unsigned long long), hipMemcpyDeviceToHost));

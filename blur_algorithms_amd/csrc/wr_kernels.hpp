@@ -35,6 +35,50 @@
 
 namespace blur_amd {
 
+// Diagnostic builds only (-DWR_STAMPS): shader-clock stamps around the phases of a unit, summed per WAVE and written
+// behind the multiplier table (the host allocates a tail for it).  No stamp executes in a normal build.
+constexpr int kWrStampSlots = 8;
+constexpr int kWrStampTailFloats = 1 << 17;      // 4096 workgroup-waves x 8 slots x 8 bytes
+#ifdef WR_STAMPS
+#define WR_STAMP_DECL unsigned long long st_acc[kWrStampSlots] = {}; unsigned long long st_prev = __builtin_amdgcn_s_memtime()
+#define WR_STAMP(i)                                                   \
+    do {                                                              \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                           \
+        __builtin_amdgcn_sched_barrier(0);                            \
+        st_acc[i] += t_ - st_prev;                                    \
+        st_prev = t_;                                                 \
+    } while (0)
+#define WR_STAMP_FLUSH(mult, n, nwaves)                                                                                       \
+    do {                                                                                                                      \
+        if ((threadIdx.x & 63) == 0 && blockIdx.x * (nwaves) + (threadIdx.x >> 6) < 2048) {                                   \
+            unsigned long long* o_ = reinterpret_cast<unsigned long long*>(const_cast<float*>(mult) + (n)) +                  \
+                                     (static_cast<size_t>(blockIdx.x) * (nwaves) + (threadIdx.x >> 6)) * kWrStampSlots;       \
+            for (int i_ = 0; i_ < kWrStampSlots; ++i_) o_[i_] = st_acc[i_];                                                   \
+        }                                                                                                                     \
+    } while (0)
+#else
+#define WR_STAMP_DECL do { } while (0)
+#define WR_STAMP(i) do { } while (0)
+#define WR_STAMP_FLUSH(mult, n, nwaves) do { } while (0)
+#endif
+
+#ifdef WR_ABL_NOMID
+#define WR_MID_ON(on_) ((on_) && blockIdx.x == 0x7fffffff)
+#else
+#define WR_MID_ON(on_) (on_)
+#endif
+
+// Makes a per-thread value opaque to the optimiser at this point of the loop body.  Without it everything that follows
+// from a loop-invariant per-thread index (sixteen load offsets, fifteen LDS table addresses, ...) is hoisted out of the
+// persistent unit loop, kept in registers for the whole kernel and spilled (fast_kernels.hpp: 168 -> 102 VGPRs).
+template <class T_> __device__ __forceinline__ T_ wr_opaque(T_ v_)
+{
+    asm volatile("" : "+v"(v_));
+    return v_;
+}
+
 constexpr int kWrS = 256;          // points of a wave-resident sub-transform: 16 lanes x 16 registers
 constexpr int kWrSB = kWrS + 8;    // LDS stride of a sub-block (complex elements): the spare 64 bytes put the four
                                    // sub-blocks a wave works on (lane & 3) on disjoint banks when it reads them
@@ -110,12 +154,20 @@ template <int S> __device__ __forceinline__ void wr_xchg_step(float2 (&v)[16])
 }
 
 // v[r] of lane lambda  <->  v[lambda] of lane r, among the 16 lanes of a sub-block (tools/wr_model.py: transpose16)
+// (ablation builds, timing only, results are wrong: -DWR_ABL_NOTR no transposes, -DWR_ABL_NOSWAP no permlane swaps,
+//  -DWR_ABL_NODPP no DPP steps, -DWR_ABL_NOMID no middle section at all)
 __device__ __forceinline__ void wr_transpose16(float2 (&v)[16])
 {
+#ifndef WR_ABL_NOTR
+#ifndef WR_ABL_NODPP
     wr_xchg_step<0>(v);
     wr_xchg_step<1>(v);
+#endif
+#ifndef WR_ABL_NOSWAP
     wr_xchg_step<2>(v);
     wr_xchg_step<3>(v);
+#endif
+#endif
 }
 
 // per-thread constants of the middle section: tw[k] = exp(-2 pi i (lane & 15) k / 256), mm[rho] = multiplier of
@@ -198,7 +250,11 @@ template <int R0> __device__ __forceinline__ void wr_ip0_load(float2 (&v)[R0], c
 {
     v[0] = line[j];
 #pragma unroll
-    for (int q = 1; q < R0; ++q) v[q] = cmulc(line[q * kWrSB + j], tw0[(q - 1) * kWrS + j]);
+    for (int q = 1; q < R0; ++q) {
+        v[q] = cmulc(line[q * kWrSB + j], tw0[(q - 1) * kWrS + j]);
+        // at most eight twiddles in flight: read all up front, a radix-16 pass holds 30 registers of them (row pass: spills)
+        if (R0 > 10 && q % 8 == 0) __builtin_amdgcn_sched_barrier(0);
+    }
     Bfly<R0, true>::run(v);
 }
 
@@ -226,17 +282,21 @@ template <int R0> __host__ __device__ constexpr size_t wr_tw0_bytes() { return s
 // ======================================================================================
 // One workgroup per CU, persistent over (frame, strip of 2C = 8 columns).  The strip's raw bytes (24 per image row)
 // arrive by 8-byte loads issued into registers one strip ahead, are parked in an LDS byte stage and serve the three
-// channels one after the other (deinterleave_BGR, Utils.hpp:159-184, is the byte pick).  Per channel: pass 0 over the
-// C complex lines (line l = columns 2l, 2l+1; reflect-101 along the column, Source.cpp:549-551), middle, inverse pass 0,
-// and the cropped rows (Source.cpp:558) leave as 8-byte stores: the even lane of a lane pair holds row p, the odd lane
-// row p + 1 of the same two columns; one quad_perm exchange gives each lane one column with both rows.
+// channels one after the other (deinterleave_BGR, Utils.hpp:159-184, is the byte pick).  A task = (strip, channel):
+// pass 0 over the C complex lines (line l = columns 2l, 2l+1; reflect-101 along the column, Source.cpp:549-551), middle,
+// inverse pass 0, and the cropped rows (Source.cpp:558) leave as 8-byte stores: the even lane of a lane pair holds row
+// p, the odd lane row p + 1 of the same two columns; one quad_perm exchange gives each lane one column with both rows.
+//
+// Two phases and two barriers per task: butterfly j of line l reads and writes only elements (l, q, j), so the inverse
+// pass 0 of task t-1 and the pass 0 of task t are ONE phase (in place, no barrier between them; their arithmetic and
+// LDS traffic interleave), and the middle of task t is the other.
 template <int R0, int C> __host__ __device__ constexpr size_t wr_col_lds(int rows)
 {
     return wr_lines_bytes<R0, C>() + wr_tw0_bytes<R0>() + ((static_cast<size_t>(rows) + 1) * (2 * C * 3) + 15) / 16 * 16;
 }
 
-// ELO / EHI: the first ELO and the last EHI rounds k of pass 0 may touch the reflected borders or the zero tail (run-time
-// index arithmetic per element); the rounds between are interior for every thread (checked by the launcher).
+// ELO / EHI: the first ELO and the last EHI rounds k of pass 0 may touch the reflected borders or the zero tail (index
+// arithmetic per element); the rounds between are interior for every thread (checked by the launcher).
 template <int R0, int C, int T, int ELO, int EHI>
 __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ src, float* __restrict__ inter,
                                                    int rows, int cols, int pad, int npairs, int nstrips, int nunits, int aligned8,
@@ -306,6 +366,26 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
         }
     };
 
+    // per-thread, per-round constants of the two pass-0 halves (loop invariant: a handful of registers)
+    //   a_in[it]   byte address inside the stage of element (l, j - pad): interior rounds add k * 256 * RB as an immediate
+    //   a_e[it][e] the same for the edge rounds (reflected row, or the zero row)
+    //   o_out[it]  float offset inside the strip's output block of pair ((j >> 1) - (pad >> 1)), this lane's column
+    int a_in[IT0], a_e[IT0][ELO + EHI > 0 ? ELO + EHI : 1], o_out[IT0];
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) {
+        const int g = tid + T * it, l = (g >> 8) < C ? (g >> 8) : C - 1, j = g & 255;
+        a_in[it] = (j - pad) * RB + (2 * l) * CH;
+#pragma unroll
+        for (int e = 0; e < ELO + EHI; ++e) {
+            const int k = e < ELO ? e : R0 - EHI + (e - ELO);
+            int r = wr_reflect(j + k * kWrS, pad, rows);
+            r = r < 0 ? rows : r;
+            a_e[it][e] = r * RB + (2 * l) * CH;
+        }
+        o_out[it] = ((j >> 1) - (pad >> 1)) * (2 * G) + 2 * (2 * l + (j & 1));
+    }
+
+    WR_STAMP_DECL;
     const WrWalk walk = wr_walk(nunits);
     if (walk.begin < walk.end) {
         issue_strip(walk.begin);
@@ -315,68 +395,85 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
         claim_strip();
     }
     __syncthreads();
+    WR_STAMP(7);      // prologue: tables, first strip
     const size_t plane = static_cast<size_t>(nstrips) * npairs * (2 * G);     // floats per channel
+
+    // inverse pass 0 of the task whose output block is `out_blk`: LDS -> butterfly -> lane-pair exchange -> global
+    auto inverse_pass0 = [&](float* out_blk) {
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int g = wr_opaque(tid + T * it);
+            if (IT0 * T == total0 || g < total0) {
+                const int l = g >> 8, j = g & 255;
+                float2 v[R0];
+                wr_ip0_load<R0>(v, lines + l * (R0 * kWrSB), tw0, j);
+                const bool odd = (j & 1) != 0;
+                float* const ob = out_blk + wr_opaque(o_out[it]);
+#pragma unroll
+                for (int k = 0; k < R0; ++k) {
+                    // even lane: row p (slot 0) of columns 2l, 2l+1; odd lane: row p + 1 (slot 1) of the same columns
+                    const float px = wr_dpp<0xB1>(v[k].x), py = wr_dpp<0xB1>(v[k].y);
+                    const float2 o = odd ? make_float2(py, v[k].y) : make_float2(v[k].x, px);
+                    bool ok = true;
+                    if (k < ELO || k >= R0 - EHI) {
+                        const int t = ((j + k * kWrS) >> 1) - (pad >> 1);
+                        ok = t >= 0 && t < npairs;
+                    }
+                    if (ok) *reinterpret_cast<float2*>(ob + k * (kWrS / 2) * (2 * G)) = o;
+                }
+            }
+        }
+    };
+
+    float* prev_blk = nullptr;
     for (int u = walk.begin; u < walk.end; u += walk.step) {
         const int f = u / nstrips, strip = u - f * nstrips;
         for (int ch = 0; ch < CH; ++ch) {
-            // ---- pass 0: bytes -> butterfly -> twiddle -> LDS
+            // ---- phase A: inverse pass 0 of the previous task, pass 0 of this one (in place, same elements per thread)
+            if (prev_blk) inverse_pass0(prev_blk);
+            WR_STAMP(4);      // inverse pass 0 + stores
+            const uint8_t* const stage_ch = stage + ch;
 #pragma unroll
             for (int it = 0; it < IT0; ++it) {
-                int g = tid + T * it;
-                asm volatile("" : "+v"(g));
+                const int g = wr_opaque(tid + T * it);
                 if (IT0 * T == total0 || g < total0) {
                     const int l = g >> 8, j = g & 255;
                     float2 v[R0];
-                    const uint8_t* sl = stage + (2 * l) * CH + ch;
+                    const int a_in_ = wr_opaque(a_in[it]);
 #pragma unroll
                     for (int k = 0; k < R0; ++k) {
-                        int r;
-                        if (k >= ELO && k < R0 - EHI) r = j + k * kWrS - pad;      // the whole round is interior
-                        else { r = wr_reflect(j + k * kWrS, pad, rows); r = r < 0 ? rows : r; }
-                        const uint8_t* s = sl + r * RB;
+                        const uint8_t* s;
+                        if (k >= ELO && k < R0 - EHI) s = stage_ch + a_in_ + k * (kWrS * RB);      // the whole round is interior
+                        else s = stage_ch + a_e[it][k < ELO ? k : ELO + (k - (R0 - EHI))];
                         v[k] = make_float2(static_cast<float>(s[0]), static_cast<float>(s[CH]));
                     }
                     wr_p0_store<R0>(v, lines + l * (R0 * kWrSB), tw0, j);
                 }
             }
+            WR_STAMP(0);      // pass 0
             __syncthreads();
+            WR_STAMP(1);      // barrier after phase A
+            // ---- phase B: the middle (wave-resident, no barrier inside); on the strip's last channel also the hand-over
+            // of the byte stage: every byte of this strip has been read, park the next strip, request the one after
             if (ch == CH - 1) {
-                // every byte of this strip has been read: park the next strip, request the one after
                 const int un = u + walk.step;
                 if (un < walk.end) {
                     commit_strip(un);
                     if (un + walk.step < walk.end) issue_strip(un + walk.step);
                 }
             }
-            // ---- middle: wave-resident, no barrier inside
-            if (mid_on) wr_middle(lines + sbi * kWrSB, wm, lane16);
+            WR_STAMP(6);      // commit of the next strip + request of the one after (last channel only)
+            if (WR_MID_ON(mid_on)) wr_middle(lines + wr_opaque(sbi) * kWrSB, wm, wr_opaque(lane16));
+            WR_STAMP(2);      // middle
+            if (ch == CH - 1) claim_strip();      // before the next phase's stores (vmcnt retires in order)
             __syncthreads();
-            if (ch == CH - 1) claim_strip();      // before this task's stores (vmcnt retires in order)
-            // ---- inverse pass 0 -> cropped rows, pair-interleaved, strip-tiled
-            float* const out_plane = inter + (static_cast<size_t>(f) * CH + ch) * plane + static_cast<size_t>(strip) * npairs * (2 * G);
-#pragma unroll
-            for (int it = 0; it < IT0; ++it) {
-                int g = tid + T * it;
-                asm volatile("" : "+v"(g));
-                if (IT0 * T == total0 || g < total0) {
-                    const int l = g >> 8, j = g & 255;
-                    float2 v[R0];
-                    wr_ip0_load<R0>(v, lines + l * (R0 * kWrSB), tw0, j);
-                    const bool odd = (j & 1) != 0;
-                    const int col2 = 2 * (2 * l + (odd ? 1 : 0));            // float offset of this lane's column inside a pair record
-#pragma unroll
-                    for (int k = 0; k < R0; ++k) {
-                        // even lane: row p (slot 0) of columns 2l, 2l+1; odd lane: row p + 1 (slot 1) of the same columns
-                        const float px = wr_dpp<0xB1>(v[k].x), py = wr_dpp<0xB1>(v[k].y);
-                        const float2 o = odd ? make_float2(py, v[k].y) : make_float2(v[k].x, px);
-                        const int t = ((j + k * kWrS) >> 1) - (pad >> 1);
-                        if (t >= 0 && t < npairs) *reinterpret_cast<float2*>(out_plane + t * (2 * G) + col2) = o;
-                    }
-                }
-            }
-            __syncthreads();
+            WR_STAMP(3);      // barrier after phase B (+ claim)
+            prev_blk = inter + (static_cast<size_t>(f) * CH + ch) * plane + static_cast<size_t>(strip) * npairs * (2 * G);
         }
     }
+    if (prev_blk) inverse_pass0(prev_blk);
+    WR_STAMP(4);
+    WR_STAMP_FLUSH(mult, N, T / 64);
 }
 
 // ======================================================================================
@@ -386,7 +483,8 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
 // transformed together.  Pass 0 takes its input straight from global memory: thread (c, j) owns columns
 // reflect(j + 256 k - pad) (Source.cpp:525-529), one 8-byte load each (slot 0, slot 1 = re, im), requested one unit
 // ahead into registers.  The last butterfly applies interleave_BGR's "+0.5f, truncate" (Utils.hpp:189,204-206) into an
-// LDS byte stage that leaves as two whole image rows.
+// LDS byte stage that leaves as two whole image rows.  Two phases per unit, as in the column pass: {inverse pass 0 of
+// unit u-1, pass 0 of unit u} and {write-out of unit u-1, middle of unit u}.
 template <int R0> __host__ __device__ constexpr size_t wr_row_lds(int cols)
 {
     return wr_lines_bytes<R0, 3>() + wr_tw0_bytes<R0>() + kWrTwlBytes + 2 * ((static_cast<size_t>(cols) * 3 + 15) / 16 * 16);
@@ -399,6 +497,7 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
 {
     constexpr int CH = 3, C = 3, G = 8;
     constexpr int NSB = C * R0;
+    constexpr int NE = ELO + EHI > 0 ? ELO + EHI : 1;
     static_assert(T == C * kWrS, "pass 0: one butterfly per thread");
     static_assert(NSB * 16 <= T, "the middle section is one round");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -417,72 +516,62 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
     WrMid<true> wm;
     wr_mid_load<R0>(wm, lane16, mid_on ? sbi % R0 : 0, w256, mult, twl);
 
-    const int c = tid >> 8;
+    const int c = __builtin_amdgcn_readfirstlane(tid >> 8);     // the channel is the same for a whole wave: scalar
+    const int j = tid & 255;
     const size_t plane = static_cast<size_t>(nstrips) * npairs * (2 * G);
     const int strip_step = npairs * (2 * G);                     // floats between the same pair of neighbouring strips
-    // the thread's butterfly index, opaque to the optimiser: otherwise every per-thread offset that follows from it is
-    // hoisted out of the unit loop and held in registers for the whole kernel (fast_kernels.hpp: 168 -> 102 VGPRs)
-    auto my_j = [&]() -> int { int t_ = tid; asm volatile("" : "+v"(t_)); return t_ & 255; };
-    // column index of padded position j + 256 k: -1 = zero
-    auto col_of = [&](int j, int k) -> int {
-        if (k >= ELO && k < R0 - EHI) return j + k * kWrS - pad;     // interior round (launcher)
-        return wr_reflect(j + k * kWrS, pad, cols);
-    };
+    // per-thread constants (loop invariant, a handful of registers): byte offset of column j - pad inside a (channel, pair)
+    // record set -- interior rounds add k * 32 strips -- and of the reflected columns of the edge rounds (~0u: zero)
+    const int jm = j - pad;
+    const unsigned off_in = static_cast<unsigned>(((jm >> 3) * strip_step + 2 * (jm & 7)) * 4);
+    unsigned off_e[NE];
+#pragma unroll
+    for (int e = 0; e < ELO + EHI; ++e) {
+        const int k = e < ELO ? e : R0 - EHI + (e - ELO);
+        const int x = wr_reflect(j + k * kWrS, pad, cols);
+        off_e[e] = x < 0 ? ~0u : static_cast<unsigned>(((x >> 3) * strip_step + 2 * (x & 7)) * 4);
+    }
+    const unsigned round_step = static_cast<unsigned>(32 * strip_step * 4);   // bytes between rounds: 256 columns = 32 strips
+    const int st_off = jm * CH + c;                              // stage byte of column j - pad, row slot 0; slot 1 at + stage_row
+
     typedef float wr_f32x2 __attribute__((ext_vector_type(2)));
     wr_f32x2 pf[R0];
     auto issue_unit = [&](int uu) {
         const int ff = uu / npairs, tt = uu - ff * npairs;
-        const float* base = inter + (static_cast<size_t>(ff) * CH + c) * plane + static_cast<size_t>(tt) * (2 * G);
-        const int j = my_j();
+        const char* base = reinterpret_cast<const char*>(inter + (static_cast<size_t>(ff) * CH + c) * plane + static_cast<size_t>(tt) * (2 * G));
+        const unsigned off_in_ = wr_opaque(off_in);
 #pragma unroll
         for (int k = 0; k < R0; ++k) {
-            int x = col_of(j, k);
-            x = x < 0 ? 0 : x;                                   // unconditional loads, masked at use
-            pf[k] = *reinterpret_cast<const wr_f32x2*>(base + static_cast<size_t>(x >> 3) * strip_step + 2 * (x & 7));
+            unsigned off;
+            if (k >= ELO && k < R0 - EHI) off = off_in_ + k * round_step;
+            else { off = off_e[k < ELO ? k : ELO + (k - (R0 - EHI))]; off = off == ~0u ? 0u : off; }      // unconditional loads, masked at use
+            pf[k] = *reinterpret_cast<const wr_f32x2*>(base + off);
         }
     };
     auto claim_unit = [&]() {
 #pragma unroll
         for (int k = 0; k < R0; ++k) asm volatile("" ::"v"(pf[k].x), "v"(pf[k].y));
     };
-
-    const WrWalk walk = wr_walk(nunits);
-    if (walk.begin < walk.end) issue_unit(walk.begin);
-    claim_unit();
-    __syncthreads();
-    for (int u = walk.begin; u < walk.end; u += walk.step) {
-        const int f = u / npairs, t = u - f * npairs;
-        const int r0 = 2 * t - (pad & 1);                        // slot 0 row (may be -1), slot 1 row r0 + 1 (may be rows)
-        // ---- pass 0
-        {
-            float2 v[R0];
-            const int j = my_j();
+    // inverse pass 0 of the unit in `lines` -> "+0.5f, truncate" -> byte stage
+    auto inverse_pass0 = [&]() {
+        float2 v[R0];
+        const int j_ = wr_opaque(j);
+        wr_ip0_load<R0>(v, lines + c * (R0 * kWrSB), tw0, j_);
+        uint8_t* const st_a_ = stage + wr_opaque(st_off);
 #pragma unroll
-            for (int k = 0; k < R0; ++k) v[k] = col_of(j, k) >= 0 ? make_float2(pf[k].x, pf[k].y) : make_float2(0.f, 0.f);
-            if (u + walk.step < walk.end) issue_unit(u + walk.step);          // in flight across the whole unit
-            wr_p0_store<R0>(v, lines + c * (R0 * kWrSB), tw0, j);
-        }
-        __syncthreads();
-        if (mid_on) wr_middle(lines + sbi * kWrSB, wm, lane16);
-        __syncthreads();
-        // ---- inverse pass 0 -> "+0.5f, truncate" -> byte stage
-        {
-            float2 v[R0];
-            const int j = my_j();
-            wr_ip0_load<R0>(v, lines + c * (R0 * kWrSB), tw0, j);
-#pragma unroll
-            for (int k = 0; k < R0; ++k) {
-                const int x = j + k * kWrS - pad;
-                if ((k >= ELO && k < R0 - EHI) || (x >= 0 && x < cols)) {
-                    uint8_t* s = stage + x * CH + c;
-                    s[0] = static_cast<uint8_t>(static_cast<int>(v[k].x + 0.5f));
-                    s[stage_row] = static_cast<uint8_t>(static_cast<int>(v[k].y + 0.5f));
-                }
+        for (int k = 0; k < R0; ++k) {
+            bool ok = true;
+            if (k < ELO || k >= R0 - EHI) { const int x = jm + k * kWrS; ok = x >= 0 && x < cols; }
+            if (ok) {
+                uint8_t* s = st_a_ + k * (kWrS * CH);
+                s[0] = static_cast<uint8_t>(static_cast<int>(v[k].x + 0.5f));
+                s[stage_row] = static_cast<uint8_t>(static_cast<int>(v[k].y + 0.5f));
             }
         }
-        claim_unit();                 // before this unit's stores (vmcnt retires in order)
-        __syncthreads();
-        // ---- two whole image rows out
+    };
+    // the two image rows of unit (f, t) out of the stage
+    auto write_out = [&](int f, int t) {
+        const int r0 = 2 * t - (pad & 1);                        // slot 0 row (may be -1), slot 1 row r0 + 1 (may be rows)
         uint8_t* const out0 = dst + (static_cast<size_t>(f) * rows + (r0 < 0 ? 0 : r0)) * rowbytes;
         const bool ok0 = r0 >= 0, ok1 = r0 + 1 < rows;
         if (aligned16) {
@@ -499,9 +588,50 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
                 if (rb ? ok1 : ok0) out0[static_cast<size_t>(rb && ok0 ? rowbytes : 0) + i] = stage[rb * stage_row + i];
             }
         }
-        // the next unit's pass 0 writes `lines` (free: every thread has passed the barrier above) and its inverse pass 0
-        // writes the stage only after two more barriers
+    };
+
+    WR_STAMP_DECL;
+    const WrWalk walk = wr_walk(nunits);
+    if (walk.begin < walk.end) issue_unit(walk.begin);
+    claim_unit();
+    __syncthreads();
+    WR_STAMP(7);      // prologue
+    int pu = -1;      // previous unit (its inverse pass 0 and write-out are still due)
+    for (int u = walk.begin; u < walk.end; u += walk.step) {
+        // ---- phase A: inverse pass 0 of the previous unit, pass 0 of this one (in place, same elements per thread)
+        if (pu >= 0) inverse_pass0();
+        __builtin_amdgcn_sched_barrier(0);      // one half after the other: together they do not fit the register budget
+        WR_STAMP(4);      // inverse pass 0
+        {
+            float2 v[R0];
+#pragma unroll
+            for (int k = 0; k < R0; ++k) {
+                bool ok = true;
+                if (k < ELO || k >= R0 - EHI) ok = off_e[k < ELO ? k : ELO + (k - (R0 - EHI))] != ~0u;
+                v[k] = ok ? make_float2(pf[k].x, pf[k].y) : make_float2(0.f, 0.f);
+            }
+            if (u + walk.step < walk.end) issue_unit(u + walk.step);          // in flight across the whole unit
+            wr_p0_store<R0>(v, lines + c * (R0 * kWrSB), tw0, wr_opaque(j));
+        }
+        WR_STAMP(0);      // pass 0
+        __syncthreads();
+        WR_STAMP(1);
+        // ---- phase B: write-out of the previous unit (the stage is complete), middle of this one
+        if (pu >= 0) write_out(pu / npairs, pu % npairs);
+        WR_STAMP(6);      // write-out
+        if (WR_MID_ON(mid_on)) wr_middle(lines + wr_opaque(sbi) * kWrSB, wm, wr_opaque(lane16));
+        WR_STAMP(2);      // middle
+        claim_unit();     // the stores of this phase were issued a whole middle section ago
+        __syncthreads();
+        WR_STAMP(3);
+        pu = u;
     }
+    if (pu >= 0) {
+        inverse_pass0();
+        __syncthreads();
+        write_out(pu / npairs, pu % npairs);
+    }
+    WR_STAMP_FLUSH(mult, R0 * kWrS, T / 64);
 }
 
 // ======================================================================================
@@ -538,7 +668,7 @@ __global__ __launch_bounds__(T) void wr_lines_kernel(const float2* __restrict__ 
             }
         }
         __syncthreads();
-        if (mid_on) wr_middle(lines + sbi * kWrSB, wm, lane16);
+        if (WR_MID_ON(mid_on)) wr_middle(lines + wr_opaque(sbi) * kWrSB, wm, wr_opaque(lane16));
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < IT0; ++it) {
