@@ -206,18 +206,43 @@ template <int R0, bool TWL> __device__ __forceinline__ void wr_mid_load(WrMid<TW
 
 // forward 256-point transform, pointwise multiply, inverse transform of the sub-block at `sb` (LDS), in place.
 // Lane lambda (= lane16) of the sub-block's 16 lanes holds elements lambda + 16 k.
-template <bool TWL> __device__ __forceinline__ void wr_middle(float2* sb, const WrMid<TWL>& w, int lane16)
+// hook(0..3) is called at four points of the first half of the section: the kernels use it to trickle the next unit's
+// global loads into the memory system one at a time instead of in a burst (a CU-wide burst of ~1500 scattered line
+// requests stalls the issuing waves for as long as HBM needs to serve it; measured with -DWR_STAMPS).
+struct WrNoHook {
+    static constexpr bool pinned = false;
+    __device__ __forceinline__ void operator()(int, float) const {}
+};
+// a hook wrapped in scheduling barriers: its loads stay where they are written instead of being hoisted to the top
+template <class F> struct WrPinned {
+    static constexpr bool pinned = true;
+    F f;
+    // `dep`: a value the section has just computed; the hook is ordered behind it (IR passes move pure arithmetic freely)
+    __device__ __forceinline__ void operator()(int q, float dep) const
+    {
+        asm volatile("" ::"v"(dep));
+        __builtin_amdgcn_sched_barrier(0);
+        f(q);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+};
+template <class F> __device__ __forceinline__ WrPinned<F> wr_pinned(F f) { return WrPinned<F>{ f }; }
+template <bool TWL, class Hook = WrNoHook> __device__ __forceinline__ void wr_middle(float2* sb, const WrMid<TWL>& w, int lane16, Hook hook = Hook())
 {
     float2 v[16];
 #pragma unroll
     for (int k = 0; k < 16; ++k) v[k] = sb[16 * k + lane16];
+    hook(0, v[15].y);
     Bfly<16, false>::run(v);
+    hook(1, v[15].y);
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], w.w(k, lane16));
     wr_transpose16(v);
+    hook(2, v[15].y);
     Bfly<16, false>::run(v);
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = cscale(v[r], w.mm[r]);
+    hook(3, v[15].y);
     Bfly<16, true>::run(v);
 #pragma unroll
     for (int r = 1; r < 16; ++r) v[r] = cmulc(v[r], w.w(r, lane16));
@@ -275,6 +300,9 @@ __device__ __forceinline__ WrWalk wr_walk(int nunits)
 }
 
 template <int R0, int C> __host__ __device__ constexpr size_t wr_lines_bytes() { return static_cast<size_t>(C) * R0 * kWrSB * sizeof(float2); }
+// column pass: lines 4 complex elements further apart, so that the four lines a 16-lane group touches in pass 0 (lane
+// bits 1-2 select the line) fall on different banks
+template <int R0> __host__ __device__ constexpr int wr_col_line_stride() { return R0 * kWrSB + 4; }
 template <int R0> __host__ __device__ constexpr size_t wr_tw0_bytes() { return static_cast<size_t>(R0 - 1) * kWrS * sizeof(float2); }
 
 // ======================================================================================
@@ -290,9 +318,12 @@ template <int R0> __host__ __device__ constexpr size_t wr_tw0_bytes() { return s
 // Two phases and two barriers per task: butterfly j of line l reads and writes only elements (l, q, j), so the inverse
 // pass 0 of task t-1 and the pass 0 of task t are ONE phase (in place, no barrier between them; their arithmetic and
 // LDS traffic interleave), and the middle of task t is the other.
+// rows of the LDS byte stage are one dword further apart than their 6C bytes: with 24-byte rows the 64 lanes of a pass-0
+// byte read (16 rows x 4 lines) pile three deep on the 32 banks; 7 dwords per row are coprime to the bank count
+template <int C> __host__ __device__ constexpr int wr_col_stage_row() { return 2 * C * 3 + 4; }
 template <int R0, int C> __host__ __device__ constexpr size_t wr_col_lds(int rows)
 {
-    return wr_lines_bytes<R0, C>() + wr_tw0_bytes<R0>() + ((static_cast<size_t>(rows) + 1) * (2 * C * 3) + 15) / 16 * 16;
+    return static_cast<size_t>(C) * wr_col_line_stride<R0>() * sizeof(float2) + wr_tw0_bytes<R0>() + ((static_cast<size_t>(rows) + 1) * wr_col_stage_row<C>() + 15) / 16 * 16;
 }
 
 // ELO / EHI: the first ELO and the last EHI rounds k of pass 0 may touch the reflected borders or the zero tail (index
@@ -303,44 +334,57 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
                                                    const float2* __restrict__ w256, const float2* __restrict__ tw0g, const float* __restrict__ mult)
 {
     constexpr int CH = 3, G = 2 * C, RB = G * CH;
+    constexpr int RS = wr_col_stage_row<C>();        // bytes between rows of the LDS byte stage
     constexpr int NSB = C * R0;                       // sub-blocks per task
+    constexpr int LS = wr_col_line_stride<R0>();      // complex elements between lines
+    static_assert(C == 4, "lane numbering of pass 0: bit 0 = row parity, bits 1-2 = line, bits 3-5 = row pair");
     static_assert(NSB * 16 <= T && T % 64 == 0, "the middle section is one round");
     static_assert(RB % 8 == 0, "a strip row is a whole number of 8-byte pieces");
     constexpr int total0 = C * kWrS, IT0 = (total0 + T - 1) / T;
     constexpr int N = R0 * kWrS;
+    constexpr int NE = ELO + EHI > 0 ? ELO + EHI : 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* lines = reinterpret_cast<float2*>(smem);
-    float2* tw0 = lines + C * R0 * kWrSB;
-    uint8_t* stage = reinterpret_cast<uint8_t*>(tw0 + (R0 - 1) * kWrS);      // [rows + 1][RB]; row `rows` stays zero
+    float2* tw0 = lines + C * LS;
+    uint8_t* stage = reinterpret_cast<uint8_t*>(tw0 + (R0 - 1) * kWrS);      // [rows + 1][RS]; row `rows` stays zero
 
     const int tid = threadIdx.x;
     for (int i = tid; i < (R0 - 1) * kWrS; i += T) tw0[i] = tw0g[i];
-    for (int i = tid; i < RB; i += T) stage[rows * RB + i] = 0;
+    for (int i = tid; i < RS; i += T) stage[rows * RS + i] = 0;
+    // middle section: sub-block sbi = l * R0 + q at l * LS + q * kWrSB
     const int lane16 = (tid >> 2) & 15, sbi = (tid >> 6) * 4 + (tid & 3);   // wr_transpose16's lane numbering
     const bool mid_on = sbi < NSB;
+    const int sb_off = mid_on ? (sbi / R0) * LS + (sbi % R0) * kWrSB : 0;
     WrMid<false> wm;
     wr_mid_load<R0>(wm, lane16, mid_on ? sbi % R0 : 0, w256, mult);
 
-    // raw strip rows, one strip ahead, in registers: rows*3 pieces of 8 bytes
+    // raw strip rows in registers, 8-byte pieces, requested a few at a time over the three tasks before they are needed
     constexpr int PIECES = RB / 8;
     constexpr int KU = (PIECES * N + T - 1) / T;      // rows < N
+    constexpr int KP = (KU + 2) / 3;                  // pieces per task
     typedef unsigned int wr_u32x2 __attribute__((ext_vector_type(2)));
     wr_u32x2 pfu[KU];
     const size_t frame_bytes = static_cast<size_t>(rows) * cols * CH;
     const int npiece = rows * PIECES;
     auto strip_fast = [&](int uu) { const int ss = uu % nstrips; return aligned8 != 0 && (ss + 1) * G <= cols; };
-    auto issue_strip = [&](int uu) {
+    // pieces [k0, k1) of strip uu
+    auto issue_strip = [&](int uu, int k0, int k1) {
         if (!strip_fast(uu)) return;
         const int ff = uu / nstrips, ss = uu - ff * nstrips;
         const uint8_t* base = src + static_cast<size_t>(ff) * frame_bytes + static_cast<size_t>(ss) * RB;
-        int t0 = tid;
-        asm volatile("" : "+v"(t0));
+        const int t0 = wr_opaque(tid);
 #pragma unroll
         for (int k = 0; k < KU; ++k) {
+            if (k < k0 || k >= k1) continue;
             int idx = t0 + T * k;
             idx = idx < npiece ? idx : npiece - 1;              // unconditional loads: all in flight together
             const int r = idx / PIECES, d = idx - r * PIECES;
+#ifdef WR_ABL_NOLOAD
+            pfu[k] = wr_u32x2{ static_cast<unsigned>(r), static_cast<unsigned>(d) };
+            (void)base;
+#else
             pfu[k] = *reinterpret_cast<const wr_u32x2*>(base + static_cast<size_t>(r) * cols * CH + 8 * d);
+#endif
         }
     };
     auto claim_strip = [&]() {
@@ -352,7 +396,12 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
 #pragma unroll
             for (int k = 0; k < KU; ++k) {
                 const int idx = tid + T * k;
-                if (idx < npiece) reinterpret_cast<wr_u32x2*>(stage)[idx] = pfu[k];
+                if (idx < npiece) {
+                    const int r = idx / PIECES, d = idx - r * PIECES;
+                    unsigned* o = reinterpret_cast<unsigned*>(stage + r * RS + 8 * d);      // rows are 4-byte aligned only
+                    o[0] = pfu[k].x;
+                    o[1] = pfu[k].y;
+                }
             }
         } else {
             // ragged last strip or rows that are not 8-byte aligned: byte loads, columns beyond the image are zero
@@ -361,26 +410,31 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
             for (int idx = tid; idx < rows * RB; idx += T) {
                 const int r = idx / RB, b = idx - r * RB;
                 const int col = ss * G + b / CH;
-                stage[idx] = col < cols ? base[(static_cast<size_t>(r) * cols + col) * CH + (b % CH)] : static_cast<uint8_t>(0);
+                stage[r * RS + b] = col < cols ? base[(static_cast<size_t>(r) * cols + col) * CH + (b % CH)] : static_cast<uint8_t>(0);
             }
         }
     };
 
+    // Pass-0 butterfly g (0 .. C*256-1) -> (line l, butterfly j): inside a wave, lane bit 0 = j & 1 (the two rows of a
+    // pair), bits 1-2 = l, bits 3-5 = (j >> 1) & 7.  The eight lanes of a row pair then hold the pair's whole 64-byte
+    // record, and a wave's store covers eight consecutive records: 512 contiguous bytes.
+    auto line_of = [](int g) { return (g >> 1) & 3; };
+    auto bfly_of = [](int g) { return ((g >> 6) << 4) | (((g >> 3) & 7) << 1) | (g & 1); };
     // per-thread, per-round constants of the two pass-0 halves (loop invariant: a handful of registers)
-    //   a_in[it]   byte address inside the stage of element (l, j - pad): interior rounds add k * 256 * RB as an immediate
+    //   a_in[it]   byte address inside the stage of element (l, j - pad): interior rounds add k * 256 * RS as an immediate
     //   a_e[it][e] the same for the edge rounds (reflected row, or the zero row)
     //   o_out[it]  float offset inside the strip's output block of pair ((j >> 1) - (pad >> 1)), this lane's column
-    int a_in[IT0], a_e[IT0][ELO + EHI > 0 ? ELO + EHI : 1], o_out[IT0];
+    int a_in[IT0], a_e[IT0][NE], o_out[IT0];
 #pragma unroll
     for (int it = 0; it < IT0; ++it) {
-        const int g = tid + T * it, l = (g >> 8) < C ? (g >> 8) : C - 1, j = g & 255;
-        a_in[it] = (j - pad) * RB + (2 * l) * CH;
+        const int g = tid + T * it, l = line_of(g), j = bfly_of(g) & 255;
+        a_in[it] = (j - pad) * RS + (2 * l) * CH;
 #pragma unroll
         for (int e = 0; e < ELO + EHI; ++e) {
             const int k = e < ELO ? e : R0 - EHI + (e - ELO);
             int r = wr_reflect(j + k * kWrS, pad, rows);
             r = r < 0 ? rows : r;
-            a_e[it][e] = r * RB + (2 * l) * CH;
+            a_e[it][e] = r * RS + (2 * l) * CH;
         }
         o_out[it] = ((j >> 1) - (pad >> 1)) * (2 * G) + 2 * (2 * l + (j & 1));
     }
@@ -388,11 +442,10 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
     WR_STAMP_DECL;
     const WrWalk walk = wr_walk(nunits);
     if (walk.begin < walk.end) {
-        issue_strip(walk.begin);
+        issue_strip(walk.begin, 0, KU);
         claim_strip();
         commit_strip(walk.begin);
-        if (walk.begin + walk.step < walk.end) issue_strip(walk.begin + walk.step);
-        claim_strip();
+        if (walk.begin + walk.step < walk.end) issue_strip(walk.begin + walk.step, 0, KP);      // as the last task of a strip before would have
     }
     __syncthreads();
     WR_STAMP(7);      // prologue: tables, first strip
@@ -404,9 +457,9 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
         for (int it = 0; it < IT0; ++it) {
             const int g = wr_opaque(tid + T * it);
             if (IT0 * T == total0 || g < total0) {
-                const int l = g >> 8, j = g & 255;
+                const int l = line_of(g), j = bfly_of(g);
                 float2 v[R0];
-                wr_ip0_load<R0>(v, lines + l * (R0 * kWrSB), tw0, j);
+                wr_ip0_load<R0>(v, lines + l * LS, tw0, j);
                 const bool odd = (j & 1) != 0;
                 float* const ob = out_blk + wr_opaque(o_out[it]);
 #pragma unroll
@@ -419,7 +472,13 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
                         const int t = ((j + k * kWrS) >> 1) - (pad >> 1);
                         ok = t >= 0 && t < npairs;
                     }
-                    if (ok) *reinterpret_cast<float2*>(ob + k * (kWrS / 2) * (2 * G)) = o;
+#ifdef WR_ABL_NOSTORE
+                    asm volatile("" ::"v"(o.x), "v"(o.y), "v"(ob));
+                    if (false)
+#else
+                    if (ok)
+#endif
+                        *reinterpret_cast<float2*>(ob + k * (kWrS / 2) * (2 * G)) = o;
                 }
             }
         }
@@ -437,35 +496,43 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
             for (int it = 0; it < IT0; ++it) {
                 const int g = wr_opaque(tid + T * it);
                 if (IT0 * T == total0 || g < total0) {
-                    const int l = g >> 8, j = g & 255;
+                    const int l = line_of(g), j = bfly_of(g);
                     float2 v[R0];
                     const int a_in_ = wr_opaque(a_in[it]);
 #pragma unroll
                     for (int k = 0; k < R0; ++k) {
                         const uint8_t* s;
-                        if (k >= ELO && k < R0 - EHI) s = stage_ch + a_in_ + k * (kWrS * RB);      // the whole round is interior
+                        if (k >= ELO && k < R0 - EHI) s = stage_ch + a_in_ + k * (kWrS * RS);      // the whole round is interior
                         else s = stage_ch + a_e[it][k < ELO ? k : ELO + (k - (R0 - EHI))];
                         v[k] = make_float2(static_cast<float>(s[0]), static_cast<float>(s[CH]));
                     }
-                    wr_p0_store<R0>(v, lines + l * (R0 * kWrSB), tw0, j);
+                    wr_p0_store<R0>(v, lines + l * LS, tw0, j);
                 }
             }
             WR_STAMP(0);      // pass 0
             __syncthreads();
             WR_STAMP(1);      // barrier after phase A
-            // ---- phase B: the middle (wave-resident, no barrier inside); on the strip's last channel also the hand-over
-            // of the byte stage: every byte of this strip has been read, park the next strip, request the one after
-            if (ch == CH - 1) {
-                const int un = u + walk.step;
-                if (un < walk.end) {
-                    commit_strip(un);
-                    if (un + walk.step < walk.end) issue_strip(un + walk.step);
+            // ---- phase B: the middle (wave-resident, no barrier inside).  The byte stage changes hands on the strip's
+            // last channel (every byte of this strip has been read: park the next strip); the strip after that is
+            // requested piece by piece from inside the middle sections of three tasks.
+            const int un = u + walk.step;
+            if (ch == CH - 1 && un < walk.end) commit_strip(un);
+            WR_STAMP(6);      // commit of the next strip (last channel only)
+            // last channel: the first third of the strip after the next; channel 0: the other two thirds of the next
+            // strip; channel 1: nothing, and the claim at its end finds loads that are a whole task old
+            const int target = ch == CH - 1 ? un + walk.step : un;
+            constexpr int KQ = (KP + 3) / 4, KQ2 = (2 * KP + 3) / 4;          // pieces per hook call
+            auto hook = wr_pinned([&](int q) {
+                if (target < walk.end) {
+                    // compile-time register ranges (the piece registers must never be indexed dynamically)
+                    if (ch == CH - 1) issue_strip(target, q * KQ, (q + 1) * KQ < KP ? (q + 1) * KQ : KP);
+                    else if (ch == 0) issue_strip(target, KP + q * KQ2, KP + (q + 1) * KQ2 < KU ? KP + (q + 1) * KQ2 : KU);
                 }
-            }
-            WR_STAMP(6);      // commit of the next strip + request of the one after (last channel only)
-            if (WR_MID_ON(mid_on)) wr_middle(lines + wr_opaque(sbi) * kWrSB, wm, wr_opaque(lane16));
+            });
+            if (WR_MID_ON(mid_on)) wr_middle(lines + wr_opaque(sb_off), wm, wr_opaque(lane16), hook);
+            else { hook(0, 0.f); hook(1, 0.f); hook(2, 0.f); hook(3, 0.f); }
             WR_STAMP(2);      // middle
-            if (ch == CH - 1) claim_strip();      // before the next phase's stores (vmcnt retires in order)
+            if (ch == 1) claim_strip();      // the strip that is parked next; before the next phase's stores (vmcnt retires in order)
             __syncthreads();
             WR_STAMP(3);      // barrier after phase B (+ claim)
             prev_blk = inter + (static_cast<size_t>(f) * CH + ch) * plane + static_cast<size_t>(strip) * npairs * (2 * G);
@@ -513,7 +580,10 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
     wr_twl_fill(twl, w256, tid, T);
     const int lane16 = (tid >> 2) & 15, sbi = (tid >> 6) * 4 + (tid & 3);   // wr_transpose16's lane numbering
     const bool mid_on = sbi < NSB;
-    WrMid<true> wm;
+#ifndef WR_ROW_TWL
+#define WR_ROW_TWL 0      // 1: the 256-point twiddles of the middle section are read from LDS where used; 0: 30 registers (measured: 0.8 us per 4K frame faster)
+#endif
+    WrMid<(WR_ROW_TWL != 0)> wm;
     wr_mid_load<R0>(wm, lane16, mid_on ? sbi % R0 : 0, w256, mult, twl);
 
     const int c = __builtin_amdgcn_readfirstlane(tid >> 8);     // the channel is the same for a whole wave: scalar
@@ -536,18 +606,28 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
 
     typedef float wr_f32x2 __attribute__((ext_vector_type(2)));
     wr_f32x2 pf[R0];
-    auto issue_unit = [&](int uu) {
+    auto unit_base = [&](int uu) -> const char* {
         const int ff = uu / npairs, tt = uu - ff * npairs;
-        const char* base = reinterpret_cast<const char*>(inter + (static_cast<size_t>(ff) * CH + c) * plane + static_cast<size_t>(tt) * (2 * G));
+        return reinterpret_cast<const char*>(inter + (static_cast<size_t>(ff) * CH + c) * plane + static_cast<size_t>(tt) * (2 * G));
+    };
+    // rounds [k0, k1) of the unit whose (channel, pair) records start at `base`
+    auto issue_part = [&](const char* base, int k0, int k1) {
         const unsigned off_in_ = wr_opaque(off_in);
 #pragma unroll
         for (int k = 0; k < R0; ++k) {
+            if (k < k0 || k >= k1) continue;
             unsigned off;
             if (k >= ELO && k < R0 - EHI) off = off_in_ + k * round_step;
             else { off = off_e[k < ELO ? k : ELO + (k - (R0 - EHI))]; off = off == ~0u ? 0u : off; }      // unconditional loads, masked at use
+#ifdef WR_ABL_NOLOAD      // ablation build (timing only, results are wrong): no global reads
+            pf[k] = wr_f32x2{ static_cast<float>(off & 255u), 1.f };
+#else
             pf[k] = *reinterpret_cast<const wr_f32x2*>(base + off);
+#endif
         }
     };
+    auto issue_unit = [&](int uu) { issue_part(unit_base(uu), 0, R0); };
+    constexpr int QP = (R0 + 3) / 4;      // rounds per quarter
     auto claim_unit = [&]() {
 #pragma unroll
         for (int k = 0; k < R0; ++k) asm volatile("" ::"v"(pf[k].x), "v"(pf[k].y));
@@ -578,7 +658,13 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
             const int nchunk = rowbytes >> 4;
             for (int idx = tid; idx < 2 * nchunk; idx += T) {
                 const int rb = idx >= nchunk ? 1 : 0, i = idx - rb * nchunk;
+#ifdef WR_ABL_NOSTORE     // ablation build: no global writes, values kept alive
+                const uint4 q_ = *reinterpret_cast<const uint4*>(stage + rb * stage_row + 16 * i);
+                asm volatile("" ::"v"(q_.x), "v"(q_.y), "v"(q_.z), "v"(q_.w), "v"(out0));
+                if (false)
+#else
                 if (rb ? ok1 : ok0)
+#endif
                     *reinterpret_cast<uint4*>(out0 + static_cast<size_t>(rb && ok0 ? rowbytes : 0) + 16 * i) =
                         *reinterpret_cast<const uint4*>(stage + rb * stage_row + 16 * i);
             }
@@ -610,7 +696,6 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
                 if (k < ELO || k >= R0 - EHI) ok = off_e[k < ELO ? k : ELO + (k - (R0 - EHI))] != ~0u;
                 v[k] = ok ? make_float2(pf[k].x, pf[k].y) : make_float2(0.f, 0.f);
             }
-            if (u + walk.step < walk.end) issue_unit(u + walk.step);          // in flight across the whole unit
             wr_p0_store<R0>(v, lines + c * (R0 * kWrSB), tw0, wr_opaque(j));
         }
         WR_STAMP(0);      // pass 0
@@ -619,9 +704,15 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
         // ---- phase B: write-out of the previous unit (the stage is complete), middle of this one
         if (pu >= 0) write_out(pu / npairs, pu % npairs);
         WR_STAMP(6);      // write-out
-        if (WR_MID_ON(mid_on)) wr_middle(lines + wr_opaque(sbi) * kWrSB, wm, wr_opaque(lane16));
+        // the next unit's input is requested a quarter at a time from inside the middle section
+        const int un = u + walk.step;
+        const char* const nbase = unit_base(un < walk.end ? un : u);          // past the end: this unit again (the data is not used)
+        auto hook = wr_pinned([&](int q) { issue_part(nbase, q * QP, (q + 1) * QP < R0 ? (q + 1) * QP : R0); });
+        if (WR_MID_ON(mid_on)) wr_middle(lines + wr_opaque(sbi) * kWrSB, wm, wr_opaque(lane16), hook);
+        else { hook(0, 0.f); hook(1, 0.f); hook(2, 0.f); hook(3, 0.f); }
         WR_STAMP(2);      // middle
-        claim_unit();     // the stores of this phase were issued a whole middle section ago
+        // (no wait for the requested rows here: the barrier must not wait on memory latency.  Nothing else is issued to
+        //  memory before pass 0 consumes them, so the wait the compiler places there counts exactly these loads.)
         __syncthreads();
         WR_STAMP(3);
         pu = u;
