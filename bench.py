@@ -9,6 +9,12 @@ over this rank's batch of FRAMES synthetic 4K RGB frames that are already reside
 Frames are independent, so ranks shard the batch with no data-path collective (weak scaling:
 FRAMES frames per GPU per step).  Rank 0 prints ONE JSON line.
 
+Launch: with --gpus N > 1 and no WORLD_SIZE in the environment this script starts its own N ranks
+(`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` as a CHILD process,
+before anything in this process touches a GPU) and relays rank 0's line; it refuses when fewer than N devices are
+visible.  `--rehearse` replaces the GPU step by a sleep so that the launch / reduce / report path runs on a CPU-only
+box (tests/test_sharding_gloo.py).
+
 Extra objects in that line:
   roofline     -- for the slower of the two kernels: algorithmic bytes per launch
                   (15 B/px x the pixels of the frames that launch covers: 3 u8 in + 12 f32 out
@@ -63,21 +69,73 @@ def baseline_metric():
         return "megapixels/sec Gaussian blur (\u03c3=20, 4K RGB) at 1/2/4/8 GPUs; % HBM roofline"
 
 
-def pmc_traffic(role, frames_per_launch):
+def pmc_traffic(role, frames_per_launch, wave_resident=True):
     """(kernel name, HBM bytes per launch) of the row / column kernel from the committed rocprofv3 PMC summary
     (separate FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 corrections applied there); the
     bytes are None when the summary is missing or was taken with another batching"""
-    default = {"row": "fast_rowpass_u8", "col": "fast_colpass_u8"}[role]
+    default = {True: {"row": "wr_rowpass_u8", "col": "wr_colpass_u8"}, False: {"row": "fast_rowpass3_u8", "col": "fast_colpass_u8"}}[wave_resident][role]
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         t = json.load(open(path))
-        name = [k for k in t if role + "pass" in k][0]
+        name = [k for k in t if role + "pass" in k and k.startswith("wr_") == wave_resident][0]
         e = t[name]
         if abs(e["frames_per_launch"] - frames_per_launch) > 1e-9:
             return name, None
         return name, e["hbm_bytes_per_launch"]
     except Exception:
         return default, None
+
+
+def self_launch(args, argv):
+    """--gpus N without torchrun: start N ranks as a child torch.distributed.run and relay rank 0's JSON line.
+    Nothing in THIS process may have initialised the GPU (device_count() does not, on this image)."""
+    import socket
+    import subprocess
+    if not args.rehearse and not args.all_on_device0:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("--gpus %d but only %d device(s) visible" % (args.gpus, have))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    p = subprocess.run(cmd, env=env)
+    raise SystemExit(p.returncode)
+
+
+def percentiles(ms):
+    """median, p10, p90 of per-step milliseconds"""
+    a = sorted(ms)
+    def q(f):
+        if not a:
+            return None
+        x = f * (len(a) - 1)
+        lo = int(x)
+        hi = min(lo + 1, len(a) - 1)
+        return a[lo] + (a[hi] - a[lo]) * (x - lo)
+    return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4)}
+
+
+def copy_bandwidth(torch, dev, mib=1024, reps=5):
+    """the box's streaming-copy rate in GB/s (bytes read + bytes written), beside the 8 TB/s spec figure"""
+    n = mib << 20
+    a = torch.empty(n, dtype=torch.uint8, device=dev)
+    b = torch.empty(n, dtype=torch.uint8, device=dev)
+    a.zero_()
+    b.copy_(a)
+    torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
 def main():
@@ -100,21 +158,57 @@ def main():
                     help="A/B: the wave-resident kernels (columns first, N = 256 R0) or the rows-first kernels of round 1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-natural", action="store_true", help="skip the second (natural-image) timed run")
+    ap.add_argument("--no-copy", action="store_true", help="skip the streaming-copy bandwidth measurement")
+    ap.add_argument("--rehearse", action="store_true", help="no GPU work: the step is a sleep (launch / reduce / report path on a CPU-only box)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])          # does not return
 
     import torch
     import torch.distributed as dist
-    import blur_algorithms_amd as B
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    rows, cols, sigma, F = args.rows, args.cols, args.sigma, args.frames
+
+    if args.rehearse:
+        # launch / barrier / reduce / report path only: no GPU, no library; the "step" sleeps 1 ms
+        if world > 1:
+            dist.init_process_group("gloo")
+        for _ in range(args.warmup):
+            time.sleep(1e-3)
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            time.sleep(1e-3)
+        if world > 1:
+            dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            print(json.dumps({"metric": baseline_metric(), "value": round(world * args.steps * F * rows * cols / 1e6 / float(t.item()), 1),
+                              "unit": "megapixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(1e3 * float(t.item()) / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "f32", "data": "rehearsal (no GPU work: sleep)", "rehearsal": True,
+                              "config": {"workload": "rehearsal of the launch path", "frames_per_gpu": F}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    import blur_algorithms_amd as B
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.all_on_device0:
         local = 0
+    if local >= torch.cuda.device_count():
+        raise SystemExit("rank %d wants cuda:%d but only %d device(s) are visible" % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -123,23 +217,22 @@ def main():
         else:
             dist.init_process_group(args.dist_backend)
 
-    rows, cols, sigma, F = args.rows, args.cols, args.sigma, args.frames
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED0000 + rank)
-    if args.data == "synthetic":
-        frames = torch.randint(0, 256, (F, rows, cols, 3), dtype=torch.uint8, device=dev, generator=g)
-    else:
+
+    def make_frames(kind):
+        if kind == "synthetic":
+            return torch.randint(0, 256, (F, rows, cols, 3), dtype=torch.uint8, device=dev, generator=g)
         import numpy as np
         tile = np.load(os.path.join(ROOT, "tests", "golden", "img_collage_top.npz"))["src"]
         reps = (-(-rows // tile.shape[0]), -(-cols // tile.shape[1]), 1)
         one = torch.from_numpy(np.ascontiguousarray(np.tile(tile, reps)[:rows, :cols])).to(dev)
-        frames = torch.stack([torch.roll(one, shifts=(17 * i, 31 * i), dims=(0, 1)) for i in range(F)]).contiguous()
+        return torch.stack([torch.roll(one, shifts=(17 * i, 31 * i), dims=(0, 1)) for i in range(F)]).contiguous()
+
+    frames = make_frames(args.data)
     out = torch.empty_like(frames)
     ctx = B.BlurContext(local)
-
-    def step():
-        ctx.pffft_(frames, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch,
-                   wave_resident={"auto": None, "on": True, "off": False}[args.wave_resident])
+    wr = {"auto": None, "on": True, "off": False}[args.wave_resident]
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -147,28 +240,49 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    if not args.no_events:
-        ctx.timing_enable(True)
-        ctx.timing(reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    tm = ctx.timing(reset=True) if not args.no_events else None
-    ctx.timing_enable(False)
+    def timed_run(src, steps, warmup, events):
+        """W warm-up steps, then exactly `steps` timed steps between two fences; per-step GPU time from events on the launch stream"""
+        def step():
+            ctx.pffft_(src, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch, wave_resident=wr)
+        for _ in range(warmup):
+            step()
+        fence()
+        if events:
+            ctx.timing_enable(True)
+            ctx.timing(reset=True)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
+        t0 = time.perf_counter()
+        marks[0].record()
+        for i in range(steps):
+            step()
+            marks[i + 1].record()
+        fence()
+        dt = time.perf_counter() - t0
+        tm = ctx.timing(reset=True) if events else None
+        ctx.timing_enable(False)
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()), tm, per_step
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed, tm, per_step = timed_run(frames, args.steps, args.warmup, not args.no_events)
+    natural = None
+    if args.data == "synthetic" and not args.no_natural:
+        nat_elapsed, _, _ = timed_run(make_frames("natural"), args.steps, 2, False)
+        natural = nat_elapsed
+    copy_gbs = None if (args.no_copy or rank != 0) else copy_bandwidth(torch, dev)
 
     if rank == 0:
         px = rows * cols
         mp_total = world * args.steps * F * px / 1e6
+        sz = B.pffft_sizing(rows, cols, sigma)
+        lib = B._lib.load() if hasattr(B, "_lib") else None
+        n_row = n_col = None
+        if lib is not None and wr is not False:
+            n_row, n_col = lib.blur_wr_length(cols + 2 * sz["pad"], 0), lib.blur_wr_length(rows + 2 * sz["pad"], 1)
+        engine = ("wave-resident kernels, columns first, engine FFT lengths %d (rows) / %d (columns)" % (n_row, n_col)) if (n_row and n_col) \
+            else "rows-first kernels at the reference's FFT lengths"
         rec = {
             "metric": baseline_metric(),
             "value": round(mp_total / elapsed, 1),
@@ -183,13 +297,16 @@ def main():
             "dtype": "f32",
             "data": args.data,
             "config": {
-                "workload": "%dx%d RGB u8 frames, sigma=%g (kSize %d), FFT row/col lengths %d/%d, %d frames per GPU per step, device-resident"
-                            % (cols, rows, sigma, B.pffft_sizing(rows, cols, sigma)["kSize"],
-                               B.pffft_sizing(rows, cols, sigma)["N1"], B.pffft_sizing(rows, cols, sigma)["N0"], F),
+                "workload": "%dx%d RGB u8 frames, sigma=%g (kSize %d), reference FFT row/col lengths %d/%d, %d frames per GPU per step, device-resident"
+                            % (cols, rows, sigma, sz["kSize"], sz["N1"], sz["N0"], F),
+                "engine": engine,
                 "frames_per_gpu": F,
                 "sharding": "frames over ranks, no data-path collective",
             },
+            "ms_per_step_gpu": percentiles(per_step),       # rank 0, HIP events around every step
         }
+        if natural is not None:
+            rec["value_natural"] = round(mp_total / natural, 1)      # same workload on natural-image frames (tests/golden crop, tiled)
         frame_bytes = 2 * ALG_BYTES_PER_PX_KERNEL * px
         rec["frame_roofline_frac"] = round((world * args.steps * F * frame_bytes / elapsed / 1e9) / (HBM_PEAK_GBS * world), 4)
         if tm and tm["row_launches"] and tm["col_launches"]:
@@ -197,16 +314,20 @@ def main():
             col_ms = tm["col_ms"] / tm["col_launches"]
             fpl = tm["row_frames"] / tm["row_launches"]            # frames one launch covers
             role, dur = ("col", col_ms) if col_ms >= row_ms else ("row", row_ms)
-            name, traffic = pmc_traffic(role, fpl)
+            wave_resident = bool(n_row and n_col)
+            name, traffic = pmc_traffic(role, fpl, wave_resident)
             alg = ALG_BYTES_PER_PX_KERNEL * px * fpl
             achieved = alg / (dur * 1e-3) / 1e9
             rec["roofline"] = {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_ms": {pmc_traffic("row", fpl)[0]: round(row_ms, 4), pmc_traffic("col", fpl)[0]: round(col_ms, 4)},
+                "avg_launch_ms": {pmc_traffic("row", fpl, wave_resident)[0]: round(row_ms, 4), pmc_traffic("col", fpl, wave_resident)[0]: round(col_ms, 4)},
                 "frames_per_launch": fpl,
                 "alg_bytes_per_launch": alg,
             }
+            if copy_gbs:
+                rec["roofline"]["copy_peak"] = round(copy_gbs, 1)           # measured streaming copy on this box, GB/s
+                rec["roofline"]["frac_of_copy"] = round(achieved / copy_gbs, 4)
         if world == 1 and not args.no_cpu:
             rec["cpu_baseline"] = cpu_baseline(rows, cols, sigma)
         print(json.dumps(rec), flush=True)

@@ -61,3 +61,25 @@ def test_two_rank_gloo_fanout_blur_fanin(nframes):
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` without torchrun must start two ranks itself (torch.distributed.run as a child) and
+    report n_gpus = 2; --rehearse replaces the GPU step by a sleep so that the launch / barrier / max-reduce / report
+    path runs on this CPU-only box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout                      # rank 0 prints ONE line
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak"
+    # a world size that does not match --gpus is an error, not a silent 1-GPU number
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    q = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse"], capture_output=True, text=True, timeout=120, env=env2)
+    assert q.returncode != 0
