@@ -33,14 +33,40 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# the CPU baseline's OpenMP threads stay where they start; set before any OpenMP runtime loads
+os.environ.setdefault("OMP_PROC_BIND", "close")
+os.environ.setdefault("OMP_PLACES", "cores")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 ALG_BYTES_PER_PX_KERNEL = 15   # per kernel; 30 B/px for the frame
 
 
+def native_oracle():
+    """the CPU port rebuilt on THIS host with -march=native (the shipped liboracle.so is x86-64-v3 so that the pinned
+    functions round alike everywhere); falls back to the shipped library when no compiler is present"""
+    import shutil
+    import subprocess
+    import tempfile
+    src = os.path.join(ROOT, "oracle")
+    cc = shutil.which("gcc")
+    if not cc:
+        return None
+    out = os.path.join(tempfile.gettempdir(), "liboracle_native_%d.so" % os.getuid())
+    cmd = [cc, "-O3", "-march=native", "-ffp-contract=off", "-fopenmp", "-fPIC", "-shared", "-o", out,
+           os.path.join(src, "blur_oracle.c"), os.path.join(src, "boxblur_oracle.c"), "-lm"]
+    try:
+        subprocess.run(cmd, check=True, capture_output=True, timeout=120)
+        return out
+    except Exception:
+        return None
+
+
 def cpu_baseline(rows, cols, sigma, budget_s=8.0):
     """time the CPU port on whole frames of the same workload for about `budget_s` seconds"""
     import numpy as np
+    native = native_oracle()
+    if native:
+        os.environ["BLUR_ORACLE_LIB"] = native
     from oracle import oracle as O
     img = np.random.default_rng(0x5EED).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
     O.pffft_blur_u8c3_f32(img, sigma)          # warm-up (page faults, OpenMP pool)
@@ -56,8 +82,9 @@ def cpu_baseline(rows, cols, sigma, budget_s=8.0):
         "unit": "megapixels/s",
         "cores": O.num_threads(),
         "kind": "port",
-        "sample": "%d frames of %dx%d RGB u8, sigma=%g, %.1f s wall, float32 OpenMP port of Source.cpp:429-570 (own radix-4/2/3/5 FFT, not pffft)"
-                  % (n, cols, rows, sigma, dt),
+        "sample": "%d frames of %dx%d RGB u8, sigma=%g, %.1f s wall, float32 OpenMP port of Source.cpp:429-570 (own radix-4/2/3/5 FFT, not pffft), "
+                  "%s, OMP_PROC_BIND=%s" % (n, cols, rows, sigma, dt, "-march=native build on this host" if native else "shipped x86-64-v3 build",
+                                           os.environ.get("OMP_PROC_BIND", "unset")),
     }
 
 

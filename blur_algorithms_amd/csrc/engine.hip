@@ -506,6 +506,8 @@ struct blur_ctx {
     size_t work2_bytes = 0;
     uint8_t* box_tmp = nullptr;
     size_t box_bytes = 0;
+    void* host_stage = nullptr;   // device staging of the host-pointer entry points (kept between calls: no allocation per frame)
+    size_t host_stage_bytes = 0;
     bool timing = false;
     std::vector<std::tuple<hipEvent_t, hipEvent_t, int, int>> ev_busy;   // start, stop, kernel (0 row / 1 column), frames
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
@@ -600,6 +602,18 @@ static int get_spectrum_custom(blur_ctx* ctx, const DevicePlan& plan, const std:
     ctx->spectra[key] = d;
     ctx->last_spectrum[plan.key] = d;
     *out = d;
+    return BLUR_OK;
+}
+
+// device staging buffer of the host-pointer entry points, grown on demand and kept in the context
+static int ensure_host_stage(blur_ctx* ctx, size_t bytes, void** out)
+{
+    if (ctx->host_stage_bytes < bytes) {
+        if (ctx->host_stage) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->host_stage)); ctx->host_stage = nullptr; ctx->host_stage_bytes = 0; }
+        HIP_TRY(ctx, hipMalloc(&ctx->host_stage, bytes ? bytes : 1));
+        ctx->host_stage_bytes = bytes;
+    }
+    *out = ctx->host_stage;
     return BLUR_OK;
 }
 
@@ -1014,6 +1028,7 @@ int blur_ctx_destroy(blur_ctx* ctx)
     if (ctx->work) (void)hipFree(ctx->work);
     if (ctx->work2) (void)hipFree(ctx->work2);
     if (ctx->box_tmp) (void)hipFree(ctx->box_tmp);
+    if (ctx->host_stage) (void)hipFree(ctx->host_stage);
     if (ctx->pipe.ready) {
         (void)hipStreamSynchronize(ctx->pipe.h2d);
         (void)hipStreamSynchronize(ctx->pipe.d2h);
@@ -1190,14 +1205,14 @@ int blur_gaussian_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int
     if (!src || !dst || rows <= 0 || cols <= 0) return fail(ctx, BLUR_ERR_INVALID, "null image or non-positive size");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bytes = static_cast<size_t>(rows) * cols * 3;
-    uint8_t* d = nullptr;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    void* dv = nullptr;
+    if (int rc0 = ensure_host_stage(ctx, bytes, &dv)) return rc0;
+    uint8_t* d = static_cast<uint8_t*>(dv);
     int rc = BLUR_OK;
     hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) rc = blur_gaussian_u8c3_dev(ctx, d, d, rows, cols, sigma, opts);
     if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) { ctx->err = std::string("host blur: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
     return rc;
 }
@@ -1264,15 +1279,15 @@ int blur_gaussian_u8c3_host_pitched(blur_ctx* ctx, const uint8_t* src, size_t sr
     if (!src || !dst || rows <= 0 || cols <= 0 || src_pitch < row_bytes || dst_pitch < row_bytes)
         return fail(ctx, BLUR_ERR_INVALID, "null image, non-positive size or pitch shorter than a row");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    uint8_t* d = nullptr;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), row_bytes * rows));
+    void* dv = nullptr;
+    if (int rc0 = ensure_host_stage(ctx, row_bytes * rows, &dv)) return rc0;
+    uint8_t* d = static_cast<uint8_t*>(dv);
     int rc = BLUR_OK;
     // the rows are packed on the way in and unpacked on the way out (cv::Mat::step of a ROI or padded Mat)
     hipError_t e = hipMemcpy2DAsync(d, row_bytes, src, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) rc = blur_gaussian_u8c3_dev(ctx, d, d, rows, cols, sigma, opts);
     if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpy2DAsync(dst, dst_pitch, d, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) { ctx->err = std::string("host blur (pitched): ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
     return rc;
 }
@@ -1283,14 +1298,14 @@ int blur_gaussian_f32c1_host(blur_ctx* ctx, const float* src, float* dst, int ro
     if (!src || !dst || rows <= 0 || cols <= 0) return fail(ctx, BLUR_ERR_INVALID, "null plane or non-positive size");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bytes = static_cast<size_t>(rows) * cols * sizeof(float);
-    float* d = nullptr;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), 2 * bytes));
+    void* dv = nullptr;
+    if (int rc0 = ensure_host_stage(ctx, 2 * bytes, &dv)) return rc0;
+    float* d = static_cast<float*>(dv);
     int rc = BLUR_OK;
     hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) rc = blur_gaussian_f32c1_dev(ctx, d, d + static_cast<size_t>(rows) * cols, rows, cols, sigma, opts);
     if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpyAsync(dst, d + static_cast<size_t>(rows) * cols, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) { ctx->err = std::string("host blur: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
     return rc;
 }
@@ -1409,14 +1424,14 @@ int blur_fastboxblur_u8_host(blur_ctx* ctx, uint8_t* inout, int w, int h, int ch
     if (!inout || w <= 0 || h <= 0 || channels <= 0) return fail(ctx, BLUR_ERR_INVALID, "fastboxblur: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bytes = static_cast<size_t>(w) * h * channels;
-    uint8_t* d = nullptr;
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), bytes));
+    void* dv = nullptr;
+    if (int rc0 = ensure_host_stage(ctx, bytes, &dv)) return rc0;
+    uint8_t* d = static_cast<uint8_t*>(dv);
     int rc = BLUR_OK;
     hipError_t e = hipMemcpyAsync(d, inout, bytes, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) rc = blur_fastboxblur_u8_dev(ctx, d, w, h, channels, ksize, passes);
     if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpyAsync(inout, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    (void)hipFree(d);
     if (e != hipSuccess) { ctx->err = std::string("host fastboxblur: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
     return rc;
 }

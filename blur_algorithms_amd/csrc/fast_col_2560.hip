@@ -4,4 +4,4 @@
 // lets 12 waves fit (156 VGPRs against 256 with the offsets hoisted).  Measured per 4K frame at sigma 50: 61.8 us
 // against 72.3 on 512 threads.
 #include "fast_kernels.hpp"
-BLUR_FAST_COL(2560, 65, 768, 0, 10, 16, 16)
+BLUR_FAST_COL(2560, 65, 768, 10, 16, 16)

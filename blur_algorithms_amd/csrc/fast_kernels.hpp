@@ -255,131 +255,6 @@ __device__ __forceinline__ void fk_mid_lds(float2* z, int zs, const float* __res
     FK_ABL_SINK(z);
 }
 
-// ---- wave-local inner section ------------------------------------------------------------------
-// After pass 0 a line falls apart into R0 independent sub-blocks of length m0 (element ranges
-// [q0*m0, (q0+1)*m0)): every later forward pass, the fused middle and every inverse pass except
-// the last stay inside one sub-block.  Each wave therefore OWNS whole sub-blocks (s = wave,
-// wave + W, ... over the R0*C sub-blocks of the workgroup's C lines) and runs all of those
-// passes on them without any workgroup barrier -- only the in-order LDS queue of the wave itself
-// orders its writes before its reads.  Barriers per line drop from 2P to 3.
-__device__ __forceinline__ void fk_wave_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-template <class PL, int I, int C, int T, bool INV>
-__device__ __forceinline__ void fk_inner_pass_wave(float2* z, int zs, const float2* twl)
-{
-    FK_ABL_DECL;
-    constexpr int R0 = PL::R[0], m0 = PL::m(0);
-    constexpr int R = PL::R[I], m = PL::m(I), nbs = m0 / R;       // butterflies per sub-block
-    constexpr int W = T / 64, S = R0 * C;
-    constexpr int off = PL::tw_off(I) - PL::lds_tw_begin();
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int total = ((S - wave + W - 1) / W) * nbs;
-    FK_UNROLL(FK_INNER_UNROLL)
-    for (int g = lane; g < total; g += 64) {
-        const int i = g / nbs, bb = g - i * nbs;
-        const int sblk = wave + W * i;
-        const int c = sblk / R0, q0 = sblk - c * R0;
-        const int blk = bb / m, j = bb - blk * m;
-        const int base = q0 * m0 + blk * (R * m) + j;
-        float2* zc = z + c * zs;
-        float2 v[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) v[k] = zc[PL::at(base + k * m)];
-        if constexpr (R <= PL::hoist_max) {
-            float2 w[R];
-#pragma unroll
-            for (int q = 1; q < R; ++q) w[q] = twl[off + (q - 1) * m + j];
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (!INV) {
-                FK_BFLY(R, false, v);
-                FK_ST(zc[PL::at(base)], v[0]);
-#pragma unroll
-                for (int q = 1; q < R; ++q) FK_ST(zc[PL::at(base + q * m)], cmul(v[q], w[q]));
-            } else {
-#pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], w[q]);
-                FK_BFLY(R, true, v);
-#pragma unroll
-                for (int k = 0; k < R; ++k) FK_ST(zc[PL::at(base + k * m)], v[k]);
-            }
-        } else {
-            if constexpr (!INV) {
-                FK_BFLY(R, false, v);
-                FK_ST(zc[PL::at(base)], v[0]);
-#pragma unroll
-                for (int q = 1; q < R; ++q) FK_ST(zc[PL::at(base + q * m)], cmul(v[q], twl[off + (q - 1) * m + j]));
-            } else {
-#pragma unroll
-                for (int q = 1; q < R; ++q) v[q] = cmulc(v[q], twl[off + (q - 1) * m + j]);
-                FK_BFLY(R, true, v);
-#pragma unroll
-                for (int k = 0; k < R; ++k) FK_ST(zc[PL::at(base + k * m)], v[k]);
-            }
-        }
-    }
-    FK_ABL_SINK(z);
-}
-
-template <class PL, int C, int T>
-__device__ __forceinline__ void fk_mid_wave(float2* z, int zs, const float* __restrict__ mpl)
-{
-    FK_ABL_DECL;
-    constexpr int R0 = PL::R[0], m0 = PL::m(0);
-    constexpr int R = PL::R[PL::P - 1], nbs = m0 / R;
-    constexpr int W = T / 64, S = R0 * C;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int total = ((S - wave + W - 1) / W) * nbs;
-    FK_UNROLL(FK_INNER_UNROLL)
-    for (int g = lane; g < total; g += 64) {
-        const int i = g / nbs, bb = g - i * nbs;
-        const int sblk = wave + W * i;
-        const int c = sblk / R0, q0 = sblk - c * R0;
-        const int base = q0 * m0 + bb * R;
-        float2* zc = z + c * zs;
-        float2 v[R];
-        float mm[R];
-#pragma unroll
-        for (int k = 0; k < R; ++k) v[k] = zc[PL::at(base + k)];
-#pragma unroll
-        for (int q = 0; q < R; ++q) mm[q] = mpl[base + q];
-        if constexpr (R <= PL::hoist_max) __builtin_amdgcn_sched_barrier(0);
-        FK_BFLY(R, false, v);
-#pragma unroll
-        for (int q = 0; q < R; ++q) v[q] = cscale(v[q], mm[q]);
-        FK_BFLY(R, true, v);
-#pragma unroll
-        for (int k = 0; k < R; ++k) FK_ST(zc[PL::at(base + k)], v[k]);
-    }
-    FK_ABL_SINK(z);
-}
-
-template <class PL, int I, int C, int T, bool INV>
-__device__ __forceinline__ void fk_inner_passes_wave(float2* z, int zs, const float2* twl)
-{
-    if constexpr (I >= 1 && I <= PL::P - 2) {
-        fk_inner_pass_wave<PL, I, C, T, INV>(z, zs, twl);
-        fk_wave_sync();
-        fk_inner_passes_wave<PL, (INV ? I - 1 : I + 1), C, T, INV>(z, zs, twl);
-    }
-}
-
-// forward inner passes, fused middle, inverse inner passes of the sub-blocks this wave owns;
-// the caller has a workgroup barrier before (pass 0 complete) and after (inverse pass 0 may start)
-template <class PL, int C, int T>
-__device__ __forceinline__ void fk_inner_section_wave(float2* z, int zs, const float2* twl, const float* __restrict__ mpl)
-{
-    static_assert(T % 64 == 0, "whole waves");
-    fk_inner_passes_wave<PL, 1, C, T, false>(z, zs, twl);
-    fk_mid_wave<PL, C, T>(z, zs, mpl);
-    fk_wave_sync();
-    fk_inner_passes_wave<PL, PL::P - 2, C, T, true>(z, zs, twl);
-}
-
 // pass-0 twiddles in registers: butterfly j = tid (+ T*it)
 template <class PL, int T> struct Pass0Regs {
     static constexpr int R = PL::R[0];
@@ -609,7 +484,7 @@ __global__ __launch_bounds__(T) void fast_rowpass3_u8(const uint8_t* __restrict_
 // ======================================================================================
 // column pass
 // ======================================================================================
-template <class PL, int T, int C, int CH, bool tiled, bool WL>
+template <class PL, int T, int C, int CH, bool tiled>
 __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const float* __restrict__ planes, uint8_t* __restrict__ dst,
                                                      int rows, int cols, int pad, int nstrips, int nunits,
                                                      const float2* __restrict__ tw, const float* __restrict__ mperm)
@@ -799,11 +674,6 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
             }
             __syncthreads();
             FK_STAMP(2);       // barrier + pass 0 + barrier
-            if constexpr (WL) {
-                fk_inner_section_wave<PL, C, T>(z, zs, twl, mpl);
-                __syncthreads();
-                FK_STAMP(4);   // wave-local inner section + barrier
-            } else {
             fk_inner_passes<PL, 1, C, T, false>(z, zs, twl);
             FK_STAMP(4);       // forward inner passes
             fk_mid_lds<PL, T, C>(z, zs, mpl);
@@ -811,7 +681,6 @@ __global__ __launch_bounds__(T, PL::col_min_waves) void fast_colpass_u8(const fl
             FK_STAMP(5);       // fused middle
             fk_inner_passes<PL, P - 2, C, T, true>(z, zs, twl);
             FK_STAMP(6);       // inverse inner passes
-            }
             // ---- inverse pass 0 -> "+0.5f, truncate" -> pixel stage (Utils.hpp:189,204-206)
             if (p0_active) {
 #pragma unroll
@@ -906,7 +775,16 @@ inline int fk_balanced_grid(int units, int slots)
     const int rounds = (units + slots - 1) / slots;
     return (units + rounds - 1) / rounds;
 }
-constexpr int kNumCUs = 256;
+// compute units of the current device (hipDeviceProp_t::multiProcessorCount), asked once
+inline int fk_num_cus()
+{
+    static const int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
 
 template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uint8_t* src, float* planes, int rows, int cols, int pad, int nframes, int tile_w,
                                                const float2* tw, const float* mperm)
@@ -930,18 +808,18 @@ template <class PL, int T> hipError_t fk_launch_row_u8(hipStream_t st, const uin
             (void)hipGetLastError();
             per_cu = 1;
         }
-        const int grid = fk_balanced_grid(nunits, kNumCUs * per_cu);
+        const int grid = fk_balanced_grid(nunits, fk_num_cus() * per_cu);
         hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, src, planes, rows, cols, pad, npairs, nunits, tw, mperm);
         return hipGetLastError();
     }
 }
 
-template <class PL, int T, int C, bool WL> hipError_t fk_launch_col_u8_c(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,
+template <class PL, int T, int C> hipError_t fk_launch_col_u8_c(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,
                                                          const float2* tw, const float* mperm)
 {
     const size_t lds = fk_col_lds<PL, C>(rows);
     if (tiled && C != 4) return hipErrorInvalidValue;          // the strip layout is 8 columns wide
-    auto kern = (tiled && C == 4) ? fast_colpass_u8<PL, T, C, 3, (C == 4), WL> : fast_colpass_u8<PL, T, C, 3, false, WL>;
+    auto kern = (tiled && C == 4) ? fast_colpass_u8<PL, T, C, 3, (C == 4)> : fast_colpass_u8<PL, T, C, 3, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
@@ -953,17 +831,17 @@ template <class PL, int T, int C, bool WL> hipError_t fk_launch_col_u8_c(hipStre
         (void)hipGetLastError();
         per_cu = 1;
     }
-    const int grid = fk_balanced_grid(nunits, kNumCUs * per_cu);
+    const int grid = fk_balanced_grid(nunits, fk_num_cus() * per_cu);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, planes, dst, rows, cols, pad, nstrips, nunits, tw, mperm);
     return hipGetLastError();
 }
 
-template <class PL, int T, bool WL> hipError_t fk_launch_col_u8(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,
+template <class PL, int T> hipError_t fk_launch_col_u8(hipStream_t st, const float* planes, uint8_t* dst, int rows, int cols, int pad, int nframes, int tiled,
                                                const float2* tw, const float* mperm, int C)
 {
     switch (C) {
-    case 4: return fk_launch_col_u8_c<PL, T, 4, WL>(st, planes, dst, rows, cols, pad, nframes, tiled, tw, mperm);
-    case 2: return fk_launch_col_u8_c<PL, T, 2, WL>(st, planes, dst, rows, cols, pad, nframes, tiled, tw, mperm);
+    case 4: return fk_launch_col_u8_c<PL, T, 4>(st, planes, dst, rows, cols, pad, nframes, tiled, tw, mperm);
+    case 2: return fk_launch_col_u8_c<PL, T, 2>(st, planes, dst, rows, cols, pad, nframes, tiled, tw, mperm);
     default: return hipErrorInvalidValue;
     }
 }
@@ -990,13 +868,13 @@ template <class PL, int T> FastEntry fk_make_row_entry()
     return e;
 }
 
-template <class PL, int T, bool WL> FastEntry fk_make_col_entry()
+template <class PL, int T> FastEntry fk_make_col_entry()
 {
     FastEntry e{};
     e.n = PL::N;
     e.npass = PL::P;
     for (int i = 0; i < PL::P; ++i) e.radix[i] = PL::R[i];
-    e.col_u8 = fk_launch_col_u8<PL, T, WL>;
+    e.col_u8 = fk_launch_col_u8<PL, T>;
     e.col_lds_bytes = fk_col_lds_bytes<PL>;
     return e;
 }
@@ -1004,8 +882,7 @@ template <class PL, int T, bool WL> FastEntry fk_make_col_entry()
 }  // namespace blur_amd
 
 // one translation unit per (FFT length, role):
-//   BLUR_FAST_ROW(4000, PAD, T, 16, 10, 5, 5)      BLUR_FAST_COL(2304, PAD, T, WL, 9, 16, 16)
-//   WL = 1: the inner passes run wave-local (no workgroup barrier between them), 0: with barriers
+//   BLUR_FAST_ROW(4000, FLAGS, T, 16, 10, 5, 5)      BLUR_FAST_COL(2304, FLAGS, T, 9, 16, 16)
 #define BLUR_FAST_ROW(NN, PAD, T, ...)                                                           \
     namespace blur_amd {                                                                         \
     const FastEntry* fast_row_entry_##NN()                                                       \
@@ -1014,11 +891,11 @@ template <class PL, int T, bool WL> FastEntry fk_make_col_entry()
         return &e;                                                                               \
     }                                                                                            \
     }
-#define BLUR_FAST_COL(NN, PAD, T, WL, ...)                                                           \
+#define BLUR_FAST_COL(NN, PAD, T, ...)                                                               \
     namespace blur_amd {                                                                         \
     const FastEntry* fast_col_entry_##NN()                                                       \
     {                                                                                            \
-        static const FastEntry e = fk_make_col_entry<StaticPlan<NN, PAD, __VA_ARGS__>, T, (WL != 0)>();     \
+        static const FastEntry e = fk_make_col_entry<StaticPlan<NN, PAD, __VA_ARGS__>, T>();                \
         return &e;                                                                               \
     }                                                                                            \
     }

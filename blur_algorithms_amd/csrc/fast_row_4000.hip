@@ -1,4 +1,4 @@
-// row role of FFT length 4000 (4K frames, sigma 20: 3840 columns + 2*60 pad + 40 zeros).
+// row role of FFT length 4000 (4K frames, sigma 20: 3840 columns + 2*65 pad + 30 zeros).
 // One workgroup of 768 threads per CU transforms the three channel lines of a row pair at once (fast_rowpass3_u8,
 // pass-0 twiddles in registers: 116 VGPRs).  16 x 25 x 10: 4000 has no 3-pass split with radices <= 16, and the
 // radix-16 first pass is exactly one round (750 butterflies).  Measured per 4K frame: 57.9 us; 16 x 10 x 25 and

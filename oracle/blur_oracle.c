@@ -632,13 +632,15 @@ int ora_pffft_blur_u8c3_f32(const uint8_t* src, uint8_t* dst, int rows, int cols
     const float divisor_row = 1.f / N1, divisor_col = 1.f / N0;                 /* :506-507 */
     float* resf = (float*)malloc(sizeof(float) * px);
 
-    for (int c = 0; c < 3; ++c) {                                               /* :510 */
-        float* plane = temp + (size_t)c * px;
+    /* one parallel region per frame: the per-thread tile buffers are allocated once, not once per channel
+       (the reference copy-constructs three vectors per TILE, Source.cpp:521,547; the port does not) */
 #pragma omp parallel
-        {
-            float* tile = (float*)malloc(sizeof(float) * (size_t)maxsize);
-            float* work = (float*)malloc(sizeof(float) * (size_t)maxsize);
-            float* tl = (float*)malloc(sizeof(float) * (size_t)maxsize);
+    {
+        float* tile = (float*)malloc(sizeof(float) * (size_t)maxsize);
+        float* work = (float*)malloc(sizeof(float) * (size_t)maxsize);
+        float* tl = (float*)malloc(sizeof(float) * (size_t)maxsize);
+        for (int c = 0; c < 3; ++c) {                                           /* :510 */
+            float* plane = temp + (size_t)c * px;
 #pragma omp for schedule(static)
             for (int j = 0; j < rows; ++j) {                                    /* :520 */
                 ora_pad_tile_f32(plane + (size_t)j * cols, cols, pad, N1, tile);/* :525-529 */
@@ -667,8 +669,8 @@ int ora_pffft_blur_u8c3_f32(const uint8_t* src, uint8_t* dst, int rows, int cols
                     for (int y = y0; y < (y0 + 64 < cols ? y0 + 64 : cols); ++y)
                         for (int x = x0; x < (x0 + 64 < rows ? x0 + 64 : rows); ++x)
                             plane[(size_t)x * cols + y] = resf[(size_t)y * rows + x];
-            free(tile); free(work); free(tl);
         }
+        free(tile); free(work); free(tl);
     }
     ora_fft_destroy_setup(cls); ora_fft_destroy_setup(rws);                     /* :565-566 */
 #pragma omp parallel for schedule(static)

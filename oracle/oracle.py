@@ -35,7 +35,8 @@ def lib():
     global _lib
     if _lib is None:
         build()
-        L = C.CDLL(_LIB)
+        # BLUR_ORACLE_LIB: bench.py's timed CPU baseline loads a -march=native rebuild made on the host it runs on
+        L = C.CDLL(os.environ.get("BLUR_ORACLE_LIB") or _LIB)
         L.ora_gaussian_window.argtypes = [C.c_double, C.c_int]
         L.ora_gaussian_window.restype = C.c_int
         L.ora_get_gaussian.argtypes = [_f32p, C.c_double, C.c_int, C.c_int]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# tools/build_variant.sh NAME ["row N FLAGS T R,R,R" | "col N FLAGS T WL R,R,R" ...]   (FLAGS: StaticPlan bits, 1 = LDS padding, 2 = late radix-16 twiddles, 4 = pass-0 twiddles in LDS)   [env: VFLAGS="-D..."]   ROLE = row | col
+# tools/build_variant.sh NAME ["row N FLAGS T R,R,R" | "col N FLAGS T R,R,R" ...]   (FLAGS: StaticPlan bits, 1 = LDS padding, 2 = late radix-16 twiddles, 4 = pass-0 twiddles in LDS)   [env: VFLAGS="-D..."]   ROLE = row | col
 # Builds blur_algorithms_amd/variants/libblur_amd_NAME.so with the given compile-time plans
 # (any (role, length) not listed keeps the plan of csrc/fast_ROLE_N.hip).  For A/B runs on the GPU box:
 #   BLUR_AMD_LIB=blur_algorithms_amd/variants/libblur_amd_NAME.so python tools/kbench.py
@@ -14,7 +14,7 @@ for spec in "$@"; do set -- $spec
 U=$(echo $1 | tr a-z A-Z)
 cat > $BD/fast_$1_$2.hip <<EOT
 #include "fast_kernels.hpp"
-BLUR_FAST_$U($2, $3, $4, $5${6:+, $6})
+BLUR_FAST_$U($2, $3, $4, $5)
 EOT
 done
 pids=""
