@@ -5,5 +5,5 @@ The product is libblur_amd.so (hand-written HIP + a C ABI, include/blur_amd.h); 
 is the thin host-side mirror of the reference's call surface over it.
 """
 from ._lib import BlurError, LIB_PATH  # noqa: F401
-from .api import (BlurContext, gaussian_window, getGaussian, isValidSize, nearestTransformSize,  # noqa: F401
+from .api import (BlurContext, BlurMulti, gaussian_window, getGaussian, isValidSize, nearestTransformSize,  # noqa: F401
                   pffft_sizing, kernel_multipliers, fft_plan_radices, box_kernel, boxfft_sizing)

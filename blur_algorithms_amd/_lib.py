@@ -58,6 +58,12 @@ SYMBOLS = {
     "blur_interleave_bgr_f32_u8_dev": (C.c_int, [_P, _P, _P, C.c_uint32]),
     "blur_fastboxblur_u8_dev": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "blur_fastboxblur_u8_host": (C.c_int, [_P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "blur_multi_create": (C.c_int, [C.POINTER(_P), C.POINTER(C.c_int), C.c_int]),
+    "blur_multi_destroy": (C.c_int, [_P]),
+    "blur_multi_shards": (C.c_int, [_P]),
+    "blur_multi_last_error": (C.c_char_p, [_P]),
+    "blur_gaussian_u8c3_batch_multi_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
+    "blur_gaussian_u8c3_batch_multi_host": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
     "blur_convolve_lines_c32_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "blur_wr_length": (C.c_int, [C.c_int, C.c_int]),
     "blur_wr_kernel_multipliers": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _P]),

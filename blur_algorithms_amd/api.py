@@ -324,3 +324,57 @@ class BlurContext:
         self.use_torch_stream()
         self._check(self._lib.blur_fastboxblur_u8_dev(self._h, image.data_ptr(), w, h, ch, int(ksize), int(passes)))
         return image
+
+
+class BlurMulti:
+    """Several GPUs (or several logical shards on one GPU) behind one handle: blur_multi_* of include/blur_amd.h.
+    Frames of a batch are sharded by frame, one context and stream per shard, driven from this one host thread."""
+
+    def __init__(self, devices):
+        self._lib = _L()
+        devs = (C.c_int * len(devices))(*[int(d) for d in devices])
+        self._h = C.c_void_p()
+        rc = self._lib.blur_multi_create(C.byref(self._h), devs, len(devices))
+        if rc:
+            raise BlurError(rc, "blur_multi_create failed")
+        self.devices = list(devices)
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.blur_multi_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc:
+            raise BlurError(rc, self._lib.blur_multi_last_error(self._h).decode())
+
+    def pffft_(self, frames, sigma, out=None, nyquist_quirk=True, wave_resident=None):
+        """frames: uint8 [n, rows, cols, 3]; a torch CUDA tensor on devices[0] or a numpy array in host memory.  Synchronous."""
+        o = BlurOpts()
+        self._lib.blur_opts_default(C.byref(o))
+        o.nyquist_quirk = 1 if nyquist_quirk else 0
+        o.reserved[3] = 0 if wave_resident is None else (2 if wave_resident else 1)
+        if isinstance(frames, np.ndarray):
+            a = np.ascontiguousarray(frames, np.uint8)
+            if a.ndim != 4 or a.shape[3] != 3:
+                raise ValueError("expected uint8 frames [n, rows, cols, 3]")
+            res = np.empty_like(a) if out is None else out
+            self._check(self._lib.blur_gaussian_u8c3_batch_multi_host(self._h, a.ctypes.data, res.ctypes.data, a.shape[0], a.shape[1], a.shape[2],
+                                                                      float(sigma), C.byref(o)))
+            return res
+        import torch
+        t = frames
+        if t.dtype != torch.uint8 or not t.is_cuda or not t.is_contiguous() or t.dim() != 4 or t.shape[-1] != 3 or t.device.index != self.devices[0]:
+            raise ValueError("expected a contiguous CUDA uint8 tensor [n, rows, cols, 3] on devices[0]")
+        dst = t if out is None else out
+        torch.cuda.synchronize(t.device)
+        self._check(self._lib.blur_gaussian_u8c3_batch_multi_dev(self._h, t.data_ptr(), dst.data_ptr(), t.shape[0], t.shape[1], t.shape[2],
+                                                                 float(sigma), C.byref(o)))
+        return dst
+

@@ -617,11 +617,23 @@ static int ensure_host_stage(blur_ctx* ctx, size_t bytes, void** out)
     return BLUR_OK;
 }
 
+// The float workspace sits between two guard bands of kWorkGuard bytes filled with 0xA5 when it is allocated;
+// blur_debug_check_workspace_guards() counts the guard bytes that no longer hold it (redzone tests).
+constexpr size_t kWorkGuard = 4096;
 static int ensure_work(blur_ctx* ctx, size_t bytes)
 {
     if (ctx->work_bytes >= bytes) return BLUR_OK;
-    if (ctx->work) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->work)); ctx->work = nullptr; ctx->work_bytes = 0; }
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->work), bytes));
+    if (ctx->work) {
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipFree(reinterpret_cast<char*>(ctx->work) - kWorkGuard));
+        ctx->work = nullptr;
+        ctx->work_bytes = 0;
+    }
+    char* base = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&base), bytes + 2 * kWorkGuard));
+    HIP_TRY(ctx, hipMemset(base, 0xA5, kWorkGuard));
+    HIP_TRY(ctx, hipMemset(base + kWorkGuard + bytes, 0xA5, kWorkGuard));
+    ctx->work = reinterpret_cast<float*>(base + kWorkGuard);
     ctx->work_bytes = bytes;
     return BLUR_OK;
 }
@@ -1025,7 +1037,7 @@ int blur_ctx_destroy(blur_ctx* ctx)
     if (ctx->d_w256) (void)hipFree(ctx->d_w256);
     for (auto& kv : ctx->wr_tw0) (void)hipFree(kv.second);
     for (auto& kv : ctx->wr_spectra) (void)hipFree(kv.second);
-    if (ctx->work) (void)hipFree(ctx->work);
+    if (ctx->work) (void)hipFree(reinterpret_cast<char*>(ctx->work) - kWorkGuard);
     if (ctx->work2) (void)hipFree(ctx->work2);
     if (ctx->box_tmp) (void)hipFree(ctx->box_tmp);
     if (ctx->host_stage) (void)hipFree(ctx->host_stage);
@@ -1438,6 +1450,126 @@ int blur_fastboxblur_u8_host(blur_ctx* ctx, uint8_t* inout, int w, int h, int ch
 
 /* diagnostic builds (-DFK_STAMPS): copy the stamp tail behind the multiplier table of FFT length n
    (role 1 = specialised row plan, 2 = specialised column plan) */
+// ---- several GPUs from one host thread ------------------------------------------------------------
+// Frames are independent (Source.cpp:510 even runs channels serially), so a batch shards by frame with no exchange
+// between the shards: shard r gets frames [n r / S, n (r + 1) / S) and its own context and stream.  `devices` may
+// repeat an ordinal: several logical shards on one GPU (that is also how the path is tested on a one-GPU box).
+struct blur_multi {
+    std::vector<int> devices;
+    std::vector<blur_ctx*> ctxs;
+    std::vector<hipStream_t> streams;
+    std::vector<uint8_t*> stage;        // per shard: frames of this shard on its device (shards away from the frames' device)
+    std::vector<size_t> stage_bytes;
+    std::string err;
+};
+
+int blur_multi_create(blur_multi** out, const int* devices, int ndevices)
+{
+    if (!out || !devices || ndevices <= 0) return BLUR_ERR_INVALID;
+    *out = nullptr;
+    auto m = std::make_unique<blur_multi>();
+    for (int r = 0; r < ndevices; ++r) {
+        blur_ctx* c = nullptr;
+        int rc = blur_ctx_create(&c, devices[r]);
+        hipStream_t st = nullptr;
+        if (rc == BLUR_OK && (hipSetDevice(devices[r]) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess)) rc = BLUR_ERR_HIP;
+        if (rc == BLUR_OK) rc = blur_ctx_set_stream(c, st);
+        if (rc != BLUR_OK) {
+            if (c) blur_ctx_destroy(c);
+            for (size_t i = 0; i < m->ctxs.size(); ++i) { blur_ctx_destroy(m->ctxs[i]); (void)hipStreamDestroy(m->streams[i]); }
+            return rc;
+        }
+        m->devices.push_back(devices[r]);
+        m->ctxs.push_back(c);
+        m->streams.push_back(st);
+        m->stage.push_back(nullptr);
+        m->stage_bytes.push_back(0);
+    }
+    *out = m.release();
+    return BLUR_OK;
+}
+
+int blur_multi_destroy(blur_multi* m)
+{
+    if (!m) return BLUR_ERR_INVALID;
+    for (size_t r = 0; r < m->ctxs.size(); ++r) {
+        (void)hipSetDevice(m->devices[r]);
+        (void)hipStreamSynchronize(m->streams[r]);
+        if (m->stage[r]) (void)hipFree(m->stage[r]);
+        blur_ctx_destroy(m->ctxs[r]);          // synchronises its stream before freeing
+        (void)hipStreamDestroy(m->streams[r]);
+    }
+    delete m;
+    return BLUR_OK;
+}
+
+int blur_multi_shards(const blur_multi* m) { return m ? static_cast<int>(m->ctxs.size()) : 0; }
+const char* blur_multi_last_error(const blur_multi* m) { return m ? m->err.c_str() : "null blur_multi"; }
+
+// location: 0 = src/dst are host pointers (pinned memory overlaps the copies of different shards), 1 = device pointers
+// on devices[0].  Synchronous: returns when every shard is done.
+static int blur_multi_run(blur_multi* m, const uint8_t* src, uint8_t* dst, int nframes, int rows, int cols, double sigma,
+                          const blur_opts* opts, int location)
+{
+    if (!m) return BLUR_ERR_INVALID;
+    if (!src || !dst || nframes < 0 || rows <= 0 || cols <= 0) { m->err = "null frame pointer, negative frame count or non-positive size"; return BLUR_ERR_INVALID; }
+    const int S = static_cast<int>(m->ctxs.size());
+    const size_t fb = static_cast<size_t>(rows) * cols * 3;
+    int rc_all = BLUR_OK;
+    for (int r = 0; r < S && rc_all == BLUR_OK; ++r) {
+        const int b = static_cast<int>(static_cast<long long>(nframes) * r / S), e = static_cast<int>(static_cast<long long>(nframes) * (r + 1) / S);
+        if (e <= b) continue;
+        const size_t bytes = fb * (e - b);
+        blur_ctx* c = m->ctxs[r];
+        hipStream_t st = m->streams[r];
+        auto hip_fail = [&](hipError_t er, const char* what) { m->err = std::string(what) + ": " + hipGetErrorString(er); rc_all = BLUR_ERR_HIP; };
+        if (hipError_t er = hipSetDevice(m->devices[r]); er != hipSuccess) { hip_fail(er, "hipSetDevice"); break; }
+        const bool local = location == 1 && m->devices[r] == m->devices[0];
+        const uint8_t* in = src + fb * b;
+        uint8_t* outp = dst + fb * b;
+        uint8_t* work_in = const_cast<uint8_t*>(in);
+        uint8_t* work_out = outp;
+        if (!local) {
+            if (m->stage_bytes[r] < bytes) {
+                if (m->stage[r]) { (void)hipStreamSynchronize(st); (void)hipFree(m->stage[r]); m->stage[r] = nullptr; m->stage_bytes[r] = 0; }
+                if (hipError_t er = hipMalloc(reinterpret_cast<void**>(&m->stage[r]), bytes); er != hipSuccess) { hip_fail(er, "hipMalloc (shard staging)"); break; }
+                m->stage_bytes[r] = bytes;
+            }
+            work_in = work_out = m->stage[r];
+            const hipError_t er = location == 0 ? hipMemcpyAsync(work_in, in, bytes, hipMemcpyHostToDevice, st)
+                                                : hipMemcpyPeerAsync(work_in, m->devices[r], in, m->devices[0], bytes, st);
+            if (er != hipSuccess) { hip_fail(er, "fan-out copy"); break; }
+        }
+        const int rc = blur_gaussian_u8c3_batch_dev(c, work_in, work_out, e - b, rows, cols, sigma, opts);
+        if (rc != BLUR_OK) { m->err = std::string("shard ") + std::to_string(r) + ": " + blur_last_error(c); rc_all = rc; break; }
+        if (!local) {
+            const hipError_t er = location == 0 ? hipMemcpyAsync(outp, work_out, bytes, hipMemcpyDeviceToHost, st)
+                                                : hipMemcpyPeerAsync(outp, m->devices[0], work_out, m->devices[r], bytes, st);
+            if (er != hipSuccess) { hip_fail(er, "fan-in copy"); break; }
+        }
+    }
+    for (int r = 0; r < S; ++r) {
+        (void)hipSetDevice(m->devices[r]);
+        const hipError_t er = hipStreamSynchronize(m->streams[r]);
+        if (er != hipSuccess && rc_all == BLUR_OK) { m->err = std::string("hipStreamSynchronize: ") + hipGetErrorString(er); rc_all = BLUR_ERR_HIP; }
+    }
+    return rc_all;
+}
+
+int blur_gaussian_u8c3_batch_multi_dev(blur_multi* m, const uint8_t* d_src, uint8_t* d_dst, int nframes, int rows, int cols, double sigma, const blur_opts* opts)
+{
+    if (m) {
+        // frames queued by the caller on devices[0] must be complete before other devices (and other streams) read them
+        if (hipSetDevice(m->devices[0]) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { m->err = "hipDeviceSynchronize on the frames' device failed"; return BLUR_ERR_HIP; }
+    }
+    return blur_multi_run(m, d_src, d_dst, nframes, rows, cols, sigma, opts, 1);
+}
+
+int blur_gaussian_u8c3_batch_multi_host(blur_multi* m, const uint8_t* src, uint8_t* dst, int nframes, int rows, int cols, double sigma, const blur_opts* opts)
+{
+    return blur_multi_run(m, src, dst, nframes, rows, cols, sigma, opts, 0);
+}
+
 int blur_convolve_lines_c32_dev(blur_ctx* ctx, const float* d_in, float* d_out, int nlines, int n, const float* multipliers)
 {
     if (!ctx) return BLUR_ERR_INVALID;
@@ -1468,6 +1600,21 @@ int blur_wr_length(int need, int column_role)
 {
     const WrEntry* e = find_wr_entry(need, column_role != 0);
     return e ? e->r0 * kWrS : 0;
+}
+
+// redzone tests: number of bytes of the workspace's two guard bands that were overwritten (0 = intact; -1 = no workspace yet)
+int blur_debug_check_workspace_guards(blur_ctx* ctx)
+{
+    if (!ctx) return -1;
+    if (!ctx->work) return -1;
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess) return -1;
+    std::vector<unsigned char> g(2 * kWorkGuard);
+    const char* base = reinterpret_cast<const char*>(ctx->work) - kWorkGuard;
+    if (hipMemcpy(g.data(), base, kWorkGuard, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(g.data() + kWorkGuard, base + kWorkGuard + ctx->work_bytes, kWorkGuard, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int bad = 0;
+    for (unsigned char c : g) bad += c != 0xA5;
+    return bad;
 }
 
 int blur_debug_read_stamps(blur_ctx* ctx, int n, int role, unsigned long long* out, int count)

@@ -180,6 +180,25 @@ int blur_fastboxblur_u8_dev(blur_ctx* ctx, uint8_t* d_inout, int w, int h, int c
 int blur_fastboxblur_u8_host(blur_ctx* ctx, uint8_t* inout, int w, int h, int channels,
                              int ksize, int passes);
 
+/* ---- several GPUs behind one handle (SURVEY.md 8(b) S1 "ctx owning a device list", 8(e)) -------------------------------
+   Frames are independent (Source.cpp:510 runs even the channels serially; the reference's only parallelism is
+   hybrid_loop over tiles, Utils.hpp:16-55), so a batch shards by frame with no exchange: shard r of S takes frames
+   [n r / S, n (r + 1) / S), has its own context (plans and kernel spectra are deterministic host code: nothing to
+   broadcast) and its own stream; one host thread drives all of them.  `devices` may repeat an ordinal (several logical
+   shards on one GPU).  Both calls are SYNCHRONOUS.
+     ..._multi_dev : frames in the memory of devices[0]; shards on other GPUs receive and return their frames by peer
+                     copies over xGMI (point to point: no ring, nothing to reduce), shards on devices[0] work in place;
+     ..._multi_host: frames in host memory (blur_host_alloc for DMA without staging); every shard copies its own slice. */
+typedef struct blur_multi blur_multi;
+int blur_multi_create(blur_multi** out, const int* devices, int ndevices);
+int blur_multi_destroy(blur_multi* m);
+int blur_multi_shards(const blur_multi* m);
+const char* blur_multi_last_error(const blur_multi* m);
+int blur_gaussian_u8c3_batch_multi_dev(blur_multi* m, const uint8_t* d_src, uint8_t* d_dst, int nframes, int rows, int cols,
+                                       double sigma, const blur_opts* opts);
+int blur_gaussian_u8c3_batch_multi_host(blur_multi* m, const uint8_t* src, uint8_t* dst, int nframes, int rows, int cols,
+                                        double sigma, const blur_opts* opts);
+
 /* ---- batched line convolution: what pffft_transform_ordered(FORWARD) -> pffft_sorted_optimized_convolution ->
    pffft_transform_ordered(BACKWARD) (Source.cpp:531-533,553-555) is per tile, for MANY lines at once --------------
    d_in / d_out: nlines complex lines of n points each (interleaved re, im floats; in == out allowed),

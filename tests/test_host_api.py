@@ -155,3 +155,29 @@ def test_wr_multipliers_reproduce_the_reference_length(L, sigma, quirk):
         assert np.array_equal(mm[1:], mm[:0:-1])            # even: two real lines may share a complex line
         got = np.fft.ifft(np.fft.fft(_reflect_tile(x, pad, n)) * mm.astype(np.float64)).real[pad:pad + L] * n
         assert np.abs(got - want).max() < 3e-5, (n, np.abs(got - want).max())    # float32 rounding of the two tables
+
+
+@pytest.mark.parametrize("sigma,n", [(20.0, 4000), (20.0, 2304), (5.0, 576), (50.0, 4320), (50.0, 2560), (2.0, 1280), (3.0, 96)])
+def test_multiplier_model_against_a_float32_transform_of_the_kernel(sigma, n):
+    """The engine computes the kernel spectrum as an exact cosine sum rounded to float once and scales it with the float
+    1.f/N (host_math.cpp: kernel_multipliers); the reference takes pffft's FLOAT32 transform of the same taps and scales
+    that (Source.cpp:485,423).  pffft is absent, so the assumption is bounded against the oracle's own float32
+    real transform (ordered layout, Source.cpp:420-425: multiplier i = kerf[2i] * scaler): the two tables differ by at
+    most 2 ULP of the DC multiplier (observed 1.0 .. 2.0), the imaginary parts the reference drops are below that too."""
+    from oracle import oracle as O
+    from blur_algorithms_amd import _lib
+    lib = _lib.load()
+    ks = lib.blur_gaussian_window(sigma, 1 << 20)
+    kerf = O.RealFFT(n).transform_ordered(O.get_gaussian(sigma, ks, n))
+    scaler = np.float32(1.0) / np.float32(n)
+    port = (kerf[0::2] * scaler).astype(np.float32)            # bins 0 .. n/2 - 1 (slot 1 holds the Nyquist bin)
+    m = np.zeros(n // 2 + 1, np.float32)
+    assert lib.blur_kernel_multipliers(sigma, ks, n, m.ctypes.data) == 0
+    ulp = float(np.spacing(np.float32(m[0])))
+    assert np.abs(m[:n // 2].astype(np.float64) - port.astype(np.float64)).max() <= 3 * ulp
+    assert np.abs(kerf[3::2].astype(np.float64)).max() * float(scaler) <= 3 * ulp
+    # the wave-resident tables at the same length are the same numbers in natural order (quirk: bin n/2 <- bin 0's rule)
+    if n % 256 == 0:
+        mm = np.zeros(n, np.float32)
+        assert lib.blur_wr_kernel_multipliers(sigma, ks, n, n, 0, mm.ctypes.data) == 0
+        assert np.abs(mm[:n // 2 + 1].astype(np.float64) - m.astype(np.float64)).max() <= 2 * ulp
