@@ -32,7 +32,7 @@ def mean_counters(sub):
     for f in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            m = re.search(r"(fast_(?:row|col)pass\d*_u8)", k)
+            m = re.search(r"((?:fast|wr)_(?:row|col)pass\d*_u8)", k)
             name = m.group(1) if m else None
             if name:
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -40,6 +40,25 @@ def mean_counters(sub):
            {k: {c: len(v) for c, v in d.items()} for k, d in acc.items()}
 
 summary = {}
+# SQ counter summary (VALU / LDS busy, bank conflicts, wait and issue-stall cycles) beside the traffic counters
+sq = {}
+for sub in ("sq_a", "sq_b", "sq_c"):
+    m, n = mean_counters(sub)
+    for k in m:
+        sq.setdefault(k, {}).update({c: round(v, 1) for c, v in m[k].items()})
+for k, d in sq.items():
+    # derived: SQ_*_CYCLES count quad-cycles summed over waves; busy fractions against the wave-cycles of the launch
+    wc = d.get("SQ_WAVE_CYCLES")
+    if wc:
+        for name, c in (("wait_frac", "SQ_WAIT_ANY"), ("issue_stall_frac", "SQ_WAIT_INST_ANY"), ("active_frac", "SQ_ACTIVE_INST_ANY"),
+                        ("valu_active_frac", "SQ_ACTIVE_INST_VALU"), ("lds_active_frac", "SQ_ACTIVE_INST_LDS")):
+            if c in d:
+                d[name] = round(d[c] / wc, 4)
+    if d.get("SQ_LDS_IDX_ACTIVE"):
+        d["lds_bank_conflict_frac"] = round(d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"], 4)
+if sq:
+    json.dump(sq, open(os.path.join(out, "%s_sq_counters.json" % tag), "w"), indent=1, sort_keys=True)
+
 for sub in ("pmc_fetch", "pmc_write", "pmc_l2"):
     m, n = mean_counters(sub)
     for k in m:
@@ -53,6 +72,9 @@ traffic = {}
 for k in sorted(summary):
     # wide (16-byte per lane, whole-line) reads are the ones FETCH_SIZE halves: the column gather and the staged
     # row input of fast_rowpass3_u8; the byte loads of fast_rowpass_u8 are reported uncorrected
+    # wr_colpass_u8 (8-byte pieces of 24-byte strip rows) and wr_rowpass_u8 (8 bytes per lane, 64-byte records): calibrated
+    # on their known input sizes -- FETCH_SIZE reads 99.97 MB for the 199.07 MB of u8 frames and 402.6 MB for the 796-800 MB
+    # of float intermediate, i.e. one half in both cases, like the wide reads: f = 2
     f = 1.0 if k == "fast_rowpass_u8" else 2.0
     if "FETCH_SIZE" in summary[k] and "WRITE_SIZE" in summary[k]:
         fetch, write = summary[k]["FETCH_SIZE"] * 1024, summary[k]["WRITE_SIZE"] * 1024
