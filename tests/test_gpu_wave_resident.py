@@ -18,8 +18,8 @@ def _rand_img(rows, cols, seed):
     return np.random.default_rng(seed).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
 
 
-@pytest.mark.parametrize("n", [2304, 4096])
-@pytest.mark.parametrize("nlines", [1, 4, 7, 1500])
+@pytest.mark.parametrize("n", [768, 1024, 1280, 1536, 2048, 2304, 2560, 3072, 3840, 4096])
+@pytest.mark.parametrize("nlines", [1, 7, 400])
 def test_convolve_lines_against_numpy(ctx, n, nlines):
     """IDFT(m * DFT(x)) of complex lines: every butterfly, twiddle, transpose and the natural-order multiplier lookup"""
     torch = _torch()
@@ -134,3 +134,37 @@ def test_wave_resident_is_the_default_on_the_metric_frame(ctx):
     c = ctx.pffft_(t, 20.0, out=torch.empty_like(t), wave_resident=False)
     assert_u8_parity(c.cpu().numpy(), want, planes)
     assert (a != c).float().mean().item() < 1e-4
+
+
+@pytest.mark.parametrize("role,r0", [("col", r) for r in (3, 4, 5, 6, 8, 9, 10)] + [("row", r) for r in (3, 4, 5, 6, 8, 9, 10, 12, 15, 16)])
+@pytest.mark.parametrize("sigma", [3.0, 20.0])
+def test_every_registered_length_in_its_role(ctx, role, r0, sigma):
+    """a thin image whose long side lands on N = 256 * R0 in the column or the row role (the other side takes the smallest
+    transform), odd sizes: every instantiated kernel runs with reflected borders, a zero tail and a ragged strip / last pair"""
+    torch = _torch()
+    import blur_algorithms_amd as B
+    from oracle import oracle as O
+    pad = B.pffft_sizing(4096, 4096, sigma)["pad"]
+    long_side = 256 * r0 - 2 * pad - 5
+    if long_side <= pad + 1:
+        pytest.skip("the transform is shorter than the kernel")
+    short = pad + 13
+    rows, cols = (long_side, short) if role == "col" else (short, long_side)
+    lib = B._lib.load()
+    assert lib.blur_wr_length(long_side + 2 * pad, 1 if role == "col" else 0) == 256 * r0
+    img = _rand_img(rows, cols, 100 + r0)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, True, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    got = ctx.pffft_(t, sigma, out=torch.empty_like(t), wave_resident=True)
+    assert_u8_parity(got.cpu().numpy(), want, planes)
+
+
+def test_config2_frame_1080p_wave_resident(ctx):
+    """BASELINE config 2 whole (1920x1080, sigma 20): column 5 x 256, row 9 x 256"""
+    torch = _torch()
+    from oracle import oracle as O
+    img = _rand_img(1080, 1920, 12)
+    want, planes = O.pffft_blur_u8c3_f64(img, 20.0, True, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    got = ctx.pffft_(t, 20.0, out=torch.empty_like(t), wave_resident=True)
+    assert_u8_parity(got.cpu().numpy(), want, planes)

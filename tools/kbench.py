@@ -12,7 +12,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--rows", type=int, default=2160); ap.add_argument("--cols", type=int, default=3840)
 ap.add_argument("--sigma", type=float, default=20.0); ap.add_argument("--frames", type=int, default=4)
 ap.add_argument("--iters", type=int, default=10); ap.add_argument("--col-group", type=int, default=0)
-ap.add_argument("--check", action="store_true"); ap.add_argument("--chunk", type=int, default=0); ap.add_argument("--row-major", action="store_true"); ap.add_argument("--tag", default="")
+ap.add_argument("--wave-resident", default="auto", choices=["auto", "on", "off"]); ap.add_argument("--check", action="store_true"); ap.add_argument("--chunk", type=int, default=0); ap.add_argument("--row-major", action="store_true"); ap.add_argument("--tag", default="")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
@@ -20,12 +20,12 @@ frames = torch.randint(0, 256, (a.frames, a.rows, a.cols, 3), dtype=torch.uint8,
 out = torch.empty_like(frames)
 ctx = B.BlurContext(0)
 for _ in range(3):
-    ctx.pffft_(frames, a.sigma, out=out, col_group=a.col_group, frames_per_launch=a.chunk, row_major_planes=a.row_major)
+    ctx.pffft_(frames, a.sigma, out=out, col_group=a.col_group, frames_per_launch=a.chunk, row_major_planes=a.row_major, wave_resident={'auto': None, 'on': True, 'off': False}[a.wave_resident])
 torch.cuda.synchronize()
 ctx.timing_enable(True); ctx.timing(reset=True)
 t0 = time.perf_counter()
 for _ in range(a.iters):
-    ctx.pffft_(frames, a.sigma, out=out, col_group=a.col_group, frames_per_launch=a.chunk, row_major_planes=a.row_major)
+    ctx.pffft_(frames, a.sigma, out=out, col_group=a.col_group, frames_per_launch=a.chunk, row_major_planes=a.row_major, wave_resident={'auto': None, 'on': True, 'off': False}[a.wave_resident])
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 tm = ctx.timing()
