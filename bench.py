@@ -165,6 +165,61 @@ def copy_bandwidth(torch, dev, mib=1024, reps=5):
     return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
 
 
+def reference_sweep(args, torch, B):
+    """Source.cpp:627-635 / py/performance.ipynb:24: x = 1500, y = 1000, +225 / +150 per step, cv::resize(Size(y, x)) -> rows = x,
+    cols = y, Test(img, flag, sqrt(x)).  Device-resident, one image per call, HIP events around the calls.  Each size also
+    checks that the kernels it ran agree with the run-time-planned kernels of the same engine (at most one grey level apart,
+    on fewer than 2e-3 of the bytes: rounding ties); parity against the float64 oracle per size is tests/test_gpu_sweep.py."""
+    import ctypes as C
+    import math
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctx = B.BlurContext(0)
+    lib = B._lib.load()
+    lib.blur_debug_last_family.argtypes = [C.c_void_p]
+    lib.blur_debug_last_family.restype = C.c_int
+    published_ms = [11.52, None]          # py/performance.ipynb:24, entry 1 (Apple M3 Pro, whole function incl. set-up)
+    rows_out = []
+    x, y = 1500, 1000
+    for i in range(45):
+        rows, cols, sigma = x, y, math.sqrt(x)
+        img = torch.randint(0, 256, (rows, cols, 3), dtype=torch.uint8, device=dev)
+        out = torch.empty_like(img)
+        sz = B.pffft_sizing(rows, cols, sigma)
+        rec = {"cols": cols, "rows": rows, "sigma": round(sigma, 2), "kSize": sz["kSize"], "N1": sz["N1"], "N0": sz["N0"]}
+        try:
+            for _ in range(2):
+                ctx.pffft_(img, sigma, out=out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            n = 5
+            e0.record()
+            for _ in range(n):
+                ctx.pffft_(img, sigma, out=out)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            ms = e0.elapsed_time(e1) / n
+            fam = lib.blur_debug_last_family(ctx._h)
+            gen = ctx.pffft_(img, sigma, out=torch.empty_like(img), force_generic=True)
+            d = (out.to(torch.int16) - gen.to(torch.int16))
+            d = (d + 128) % 256 - 128
+            rec.update({"ms": round(ms, 4), "megapixels_per_s": round(rows * cols / 1e6 / (ms * 1e-3), 1),
+                        "roofline_frac": round(30.0 * rows * cols / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "kernels": {0: "run-time plans", 1: "specialised rows-first", 2: "wave-resident"}.get(fam, "?"),
+                        "max_abs_diff_vs_generic": int(d.abs().max().item()), "frac_diff_vs_generic": round(float((d != 0).float().mean().item()), 6)})
+            rec["agrees"] = rec["max_abs_diff_vs_generic"] <= 1 and rec["frac_diff_vs_generic"] < 2e-3
+        except B.BlurError as e:
+            rec["error"] = str(e)
+        rows_out.append(rec)
+        del img, out
+        x += 225
+        y += 150
+    ok = [r for r in rows_out if "ms" in r]
+    print(json.dumps({"preset": "reference-sweep", "unit": "megapixels/s", "data": "synthetic",
+                      "published_first_entry_ms_m3pro": published_ms[0],
+                      "min_megapixels_per_s": min(r["megapixels_per_s"] for r in ok) if ok else None,
+                      "all_agree": all(r.get("agrees", False) for r in ok), "sizes": rows_out}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,6 +242,9 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-natural", action="store_true", help="skip the second (natural-image) timed run")
     ap.add_argument("--no-copy", action="store_true", help="skip the streaming-copy bandwidth measurement")
+    ap.add_argument("--preset", default="", choices=["", "reference-sweep"],
+                    help="reference-sweep: the reference's own benchmark (Source.cpp:627-635): 45 RGB images 1000x1500 ... 7600x11400, "
+                         "sigma = sqrt(longer side), one image per call; prints one JSON line with a row per size")
     ap.add_argument("--rehearse", action="store_true", help="no GPU work: the step is a sleep (launch / reduce / report path on a CPU-only box)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -232,6 +290,8 @@ def main():
     import blur_algorithms_amd as B
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.preset == "reference-sweep":
+        return reference_sweep(args, torch, B)
     if args.all_on_device0:
         local = 0
     if local >= torch.cuda.device_count():

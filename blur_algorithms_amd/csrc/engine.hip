@@ -506,6 +506,7 @@ struct blur_ctx {
     size_t work2_bytes = 0;
     uint8_t* box_tmp = nullptr;
     size_t box_bytes = 0;
+    int last_family = -1;         // kernels the last u8c3 blur used: 0 run-time plans, 1 specialised rows-first, 2 wave-resident
     void* host_stage = nullptr;   // device staging of the host-pointer entry points (kept between calls: no allocation per frame)
     size_t host_stage_bytes = 0;
     bool timing = false;
@@ -1127,6 +1128,7 @@ static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_
     if (chunk > nframes) chunk = nframes;
     if (nframes == 0) return BLUR_OK;
     if (int rc = ensure_work(ctx, p.frame_elems * sizeof(float) * chunk)) return rc;
+    ctx->last_family = p.wr_col ? 2 : ((p.row->fast && p.col->fast) ? 1 : 0);
     for (int f = 0; f < nframes; f += chunk) {
         const int nf = nframes - f < chunk ? nframes - f : chunk;
         const uint8_t* s = d_src + static_cast<size_t>(f) * px * 3;
@@ -1609,6 +1611,10 @@ int blur_wr_length(int need, int column_role)
     const WrEntry* e = find_wr_entry(need, column_role != 0);
     return e ? e->r0 * kWrS : 0;
 }
+
+// which kernels the last 8-bit 3-channel blur of this context ran: 0 run-time-planned, 1 specialised rows-first (both passes),
+// 2 wave-resident; -1 none yet (bench.py --preset reference-sweep reports it per size)
+int blur_debug_last_family(const blur_ctx* ctx) { return ctx ? ctx->last_family : -1; }
 
 // redzone tests: number of bytes of the workspace's two guard bands that were overwritten (0 = intact; -1 = no workspace yet)
 int blur_debug_check_workspace_guards(blur_ctx* ctx)
