@@ -702,7 +702,9 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
         __syncthreads();
         WR_STAMP(1);
         // ---- phase B: write-out of the previous unit (the stage is complete), middle of this one
+#ifndef WR_ROW_STORE_LATE
         if (pu >= 0) write_out(pu / npairs, pu % npairs);
+#endif
         WR_STAMP(6);      // write-out
         // the next unit's input is requested a quarter at a time from inside the middle section
         const int un = u + walk.step;
@@ -710,6 +712,9 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
         auto hook = wr_pinned([&](int q) { issue_part(nbase, q * QP, (q + 1) * QP < R0 ? (q + 1) * QP : R0); });
         if (WR_MID_ON(mid_on)) wr_middle(lines + wr_opaque(sbi) * kWrSB, wm, wr_opaque(lane16), hook);
         else { hook(0, 0.f); hook(1, 0.f); hook(2, 0.f); hook(3, 0.f); }
+#ifdef WR_ROW_STORE_LATE
+        if (pu >= 0) write_out(pu / npairs, pu % npairs);      // behind the requests for the next unit's rows
+#endif
         WR_STAMP(2);      // middle
         // (no wait for the requested rows here: the barrier must not wait on memory latency.  Nothing else is issued to
         //  memory before pass 0 consumes them, so the wait the compiler places there counts exactly these loads.)
