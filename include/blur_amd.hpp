@@ -31,6 +31,10 @@
 #include <stdexcept>
 #include <string>
 #include <type_traits>
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
+#include <thread>
 #include <vector>
 
 #include "blur_amd.h"
@@ -93,16 +97,37 @@ template <typename T> void getGaussian(T& kernel, const double sigma, int width 
     std::copy(tmp.begin(), tmp.begin() + kernel.size(), kernel.data());
 }
 
-// ---- the parallel-for of the reference (OpenMP when compiled with it, else serial) -----------
+// ---- the parallel-for of the reference (Utils.hpp:16-55) ------------------------------------
+// Same three modes, chosen the same way: -DMYLOOP (the published build, .vscode/tasks.json:21) splits [0, end) into
+// one contiguous block per hardware thread and runs them on fresh std::threads; OpenMP when compiled with it; else
+// serial.  A two-argument operation receives the number of the thread that runs the index.  (end == 0 runs nothing:
+// the reference's MYLOOP branch divides by zero there, Utils.hpp:42-44.)
 template <typename T, typename op> void hybrid_loop(T end, op operation)
 {
-#if defined(_OPENMP)
-#pragma omp parallel for
-#endif
-    for (T i = 0; i < end; ++i) {
+    auto call = [&](T i, int tid) {
         if constexpr (std::is_invocable_v<op, T>) operation(i);
-        else operation(i, 0);
-    }
+        else operation(i, tid);
+    };
+#if defined(MYLOOP) || defined(__EMSCRIPTEN_THREADS__)
+    if (!(end > 0)) return;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned long long n = static_cast<unsigned long long>(end);
+    const unsigned long long block = (n + hw - 1) / hw;
+    const unsigned nthreads = static_cast<unsigned>((n + block - 1) / block);          // never more threads than blocks
+    std::vector<std::thread> pool;
+    pool.reserve(nthreads);
+    for (unsigned t = 0; t < nthreads; ++t)
+        pool.emplace_back([&call, t, block, n] {
+            const unsigned long long b = t * block, e = std::min(n, b + block);
+            for (unsigned long long i = b; i < e; ++i) call(static_cast<T>(i), static_cast<int>(t));
+        });
+    for (auto& th : pool) th.join();
+#elif defined(_OPENMP)
+#pragma omp parallel for
+    for (T i = 0; i < end; ++i) call(i, omp_get_thread_num());
+#else
+    for (T i = 0; i < end; ++i) call(i, 0);
+#endif
 }
 
 // ---- layout utilities (host) --------------------------------------------------------------

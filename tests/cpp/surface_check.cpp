@@ -64,14 +64,15 @@ static int host_checks()
     REQUIRE(b[1] == a[5]);                             // out[x*h + y] = in[y*w + x]
     flip_block<float, 1>(b.data(), c.data(), 3, 5);
     REQUIRE(a == c);
-    int hits = 0;
-    hybrid_loop(100, [&](int) {
-#if defined(_OPENMP)
-#pragma omp atomic
-#endif
-        ++hits;
-    });
-    REQUIRE(hits == 100);
+    // hybrid_loop (Utils.hpp:16-55): every index exactly once in every build mode (-DMYLOOP: std::thread blocks),
+    // the two-argument form receives a thread number
+    std::vector<int> seen(1000, 0), tids(1000, -1);
+    hybrid_loop(1000, [&](int i) { ++seen[i]; });
+    hybrid_loop(1000, [&](int i, int tid) { tids[i] = tid; });
+    for (int i = 0; i < 1000; ++i) REQUIRE(seen[i] == 1 && tids[i] >= 0);
+    hybrid_loop(0, [&](int) { std::abort(); });        // an empty range runs nothing (the reference divides by zero here)
+    hybrid_loop(3u, [&](unsigned i) { ++seen[i]; });   // fewer indices than threads
+    REQUIRE(seen[0] == 2 && seen[2] == 2 && seen[3] == 1);
     std::printf("host ok\n");
     return 0;
 }

@@ -66,6 +66,8 @@ SMALL = [
     (500, 748, 20.0),
     (16, 16, 1.0),
     (301, 8, 1.2),
+    (700, 900, 90.0),     # pad 299 > 256: more than one edge round at each end (the general instantiation of both kernels)
+    (640, 331, 60.0),
 ]
 
 

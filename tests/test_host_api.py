@@ -108,9 +108,12 @@ def test_fastboxblur_include_path_shim_compiles(tmp_path):
     assert subprocess.run([exe]).returncode == 0
 
 
-def test_cpp_header_with_reference_names():
+@pytest.mark.parametrize("mode", [["-fopenmp"], ["-DMYLOOP", "-pthread"], []])
+def test_cpp_header_with_reference_names(mode):
+    """include/blur_amd.hpp under the reference's three hybrid_loop build modes (Utils.hpp:24-54): OpenMP, -DMYLOOP
+    (std::thread blocks: the published build, .vscode/tasks.json:21) and serial"""
     exe = os.path.join(ROOT, "tests", "cpp", "surface_check")
-    subprocess.check_call(["g++", "-std=c++17", "-O1", "-fopenmp", "-I" + os.path.join(ROOT, "include"),
+    subprocess.check_call(["g++", "-std=c++17", "-O1"] + mode + ["-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "cpp", "surface_check.cpp"),
                            "-L" + os.path.dirname(B.LIB_PATH), "-lblur_amd", "-Wl,-rpath," + os.path.dirname(B.LIB_PATH),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
