@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <new>
@@ -222,11 +223,65 @@ template <class Mat, class = decltype(std::declval<Mat&>().size[0])> void pocket
     pocketfft_1D(image, nsmooth);
 }
 
+// ---- image in / out (the role cv::imread / cv::imwrite play in main(), Source.cpp:623,635) ----------------------
+// Binary PPM (P6, maxval 255): the one format that needs no codec library.  An Image has what pffft_(Mat&, double)
+// asks of a cv::Mat: .data, .size[0] = rows, .size[1] = cols, channels().
+struct Image {
+    std::vector<uint8_t> pixels;
+    int size[2] = { 0, 0 };
+    uint8_t* data = nullptr;
+    int channels() const { return 3; }
+    bool empty() const { return pixels.empty(); }
+};
+
+inline Image imread(const std::string& path)
+{
+    Image im;
+    FILE* f = std::fopen(path.c_str(), "rb");
+    if (!f) return im;
+    auto token = [&](int& v) {                          // decimal number, comments (# ... end of line) skipped
+        int c = std::fgetc(f);
+        while (c == '#' || c == ' ' || c == '\t' || c == '\r' || c == '\n') {
+            if (c == '#') while (c != '\n' && c != EOF) c = std::fgetc(f);
+            else c = std::fgetc(f);
+        }
+        if (c < '0' || c > '9') return false;
+        v = 0;
+        while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); c = std::fgetc(f); }
+        return true;                                    // the one whitespace byte after the number is consumed
+    };
+    int w = 0, h = 0, maxv = 0;
+    const bool ok = std::fgetc(f) == 'P' && std::fgetc(f) == '6' && token(w) && token(h) && token(maxv) && w > 0 && h > 0 && maxv == 255;
+    if (ok) {
+        im.pixels.resize(static_cast<size_t>(w) * h * 3);
+        if (std::fread(im.pixels.data(), 1, im.pixels.size(), f) == im.pixels.size()) {
+            im.size[0] = h;
+            im.size[1] = w;
+            im.data = im.pixels.data();
+        } else im.pixels.clear();
+    }
+    std::fclose(f);
+    return im;
+}
+
+inline bool imwrite(const std::string& path, const Image& im)
+{
+    if (im.empty()) return false;
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) return false;
+    std::fprintf(f, "P6\n%d %d\n255\n", im.size[1], im.size[0]);
+    const bool ok = std::fwrite(im.data, 1, im.pixels.size(), f) == im.pixels.size();
+    return std::fclose(f) == 0 && ok;
+}
+
 }  // namespace compat
 }  // namespace blur_amd
 
 #ifdef BLUR_AMD_GLOBAL_NAMES
 using blur_amd::compat::AlignedVector;
+using blur_amd::compat::Image;
+using blur_amd::compat::imread;
+using blur_amd::compat::imwrite;
 using blur_amd::compat::deinterleave_BGR;
 using blur_amd::compat::fastboxblur;
 using blur_amd::compat::flip_block;

@@ -73,6 +73,25 @@ static int host_checks()
     hybrid_loop(0, [&](int) { std::abort(); });        // an empty range runs nothing (the reference divides by zero here)
     hybrid_loop(3u, [&](unsigned i) { ++seen[i]; });   // fewer indices than threads
     REQUIRE(seen[0] == 2 && seen[2] == 2 && seen[3] == 1);
+    // image files (the role of cv::imread / cv::imwrite, Source.cpp:623,635): binary PPM round trip, comments in the header
+    {
+        Image im;
+        im.size[0] = 5; im.size[1] = 7;
+        im.pixels.resize(5 * 7 * 3);
+        for (size_t i = 0; i < im.pixels.size(); ++i) im.pixels[i] = (uint8_t)(i * 37 + 11);
+        im.data = im.pixels.data();
+        const std::string path = "/tmp/blur_amd_surface_check.ppm";
+        REQUIRE(imwrite(path, im));
+        Image back2 = imread(path);
+        REQUIRE(back2.size[0] == 5 && back2.size[1] == 7 && back2.pixels == im.pixels && back2.data == back2.pixels.data());
+        FILE* f = std::fopen(path.c_str(), "wb");
+        std::fputs("P6\n# a comment\n7 5\n# another\n255\n", f);
+        std::fwrite(im.pixels.data(), 1, im.pixels.size(), f);
+        std::fclose(f);
+        Image back3 = imread(path);
+        REQUIRE(back3.pixels == im.pixels && back3.channels() == 3);
+        REQUIRE(imread("/nonexistent/file.ppm").empty());
+    }
     std::printf("host ok\n");
     return 0;
 }

@@ -149,3 +149,26 @@ def test_multi_gpu_c_abi_with_logical_shards_on_one_device(ctx, shards):
     m.pffft_(one, 4.0)
     assert torch.equal(one[0], want[0])
     m.close()
+
+
+def test_image_file_in_blur_file_out(ctx, tmp_path):
+    """decode -> GPU blur -> encode (main() of the reference, Source.cpp:611-641), in Python and through examples/blur_main.cpp"""
+    import os
+    import subprocess
+    from blur_algorithms_amd import io
+    import blur_algorithms_amd as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    img = np.random.default_rng(9).integers(0, 256, (90, 121, 3), dtype=np.uint8)
+    want = ctx.pffft_(img, 4.0)
+    src, dst = str(tmp_path / "in.png"), str(tmp_path / "out.png")
+    io.imwrite(src, img)
+    got = io.blur_file(src, dst, 4.0, ctx=ctx)
+    assert np.array_equal(got, want) and np.array_equal(io.imread(dst), want)
+    exe = str(tmp_path / "blur_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "blur_main.cpp"),
+                           "-L" + os.path.dirname(B.LIB_PATH), "-lblur_amd", "-Wl,-rpath," + os.path.dirname(B.LIB_PATH),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    ppm = str(tmp_path / "in.ppm")
+    io.imwrite(ppm, img)
+    assert subprocess.run([exe, "3", "4.0", ppm]).returncode == 0
+    assert np.array_equal(io.imread(ppm + ".out.ppm"), want)

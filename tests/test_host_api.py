@@ -184,3 +184,22 @@ def test_multiplier_model_against_a_float32_transform_of_the_kernel(sigma, n):
         mm = np.zeros(n, np.float32)
         assert lib.blur_wr_kernel_multipliers(sigma, ks, n, n, 0, mm.ctypes.data) == 0
         assert np.abs(mm[:n // 2 + 1].astype(np.float64) - m.astype(np.float64)).max() <= 2 * ulp
+
+
+def test_python_image_files_round_trip(tmp_path):
+    """blur_algorithms_amd.io: decode / encode either side of the blur (cv::imread / cv::imwrite in main(), Source.cpp:623,635)"""
+    from blur_algorithms_amd import io
+    img = np.random.default_rng(2).integers(0, 256, (37, 53, 3), dtype=np.uint8)
+    for ext in ("png", "ppm", "bmp"):
+        p = str(tmp_path / ("x." + ext))
+        io.imwrite(p, img)
+        assert np.array_equal(io.imread(p), img)
+
+
+def test_example_main_compiles(tmp_path):
+    """examples/blur_main.cpp: the reference's main() over the engine (compile and usage message only: no GPU here)"""
+    exe = str(tmp_path / "blur_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "blur_main.cpp"),
+                           "-L" + os.path.dirname(B.LIB_PATH), "-lblur_amd", "-Wl,-rpath," + os.path.dirname(B.LIB_PATH),
+                           "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    assert subprocess.run([exe], capture_output=True).returncode == 2
