@@ -53,6 +53,10 @@ SYMBOLS = {
     "blur_boxfft_sizing": (C.c_int, [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int)]),
     "blur_box_kernel": (C.c_int, [_P, C.c_int, C.c_int]),
     "blur_rowpass_u8c3_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
+    "blur_pocketfft2d_sizing": (C.c_int, [C.c_int, C.c_int, C.c_double, C.POINTER(C.c_int * 8)]),
+    "blur_pocketfft2d_u8c3_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.c_int, _P]),
+    "blur_pocketfft2d_u8c3_host": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.c_int]),
+    "blur_reflect101_u8_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int * 2)]),
     "blur_flip_block_f32_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int]),
     "blur_deinterleave_bgr_u8_f32_dev": (C.c_int, [_P, _P, _P, C.c_uint32]),
     "blur_interleave_bgr_f32_u8_dev": (C.c_int, [_P, _P, _P, C.c_uint32]),

@@ -68,6 +68,15 @@ def box_kernel(kLen, FFT_length):
     return k
 
 
+def pocketfft2d_sizing(rows, cols, sigma):
+    """the sizing block of pocketfft_2D -- Source.cpp:149-176"""
+    out = (C.c_int * 8)()
+    rc = _L().blur_pocketfft2d_sizing(int(rows), int(cols), float(sigma), out)
+    if rc:
+        raise BlurError(rc, "pocketfft2d_sizing: bad arguments")
+    return dict(kSize=out[0], pad=out[1], sizes=(out[2], out[3]), border=(out[4], out[5], out[6], out[7]))
+
+
 def boxfft_sizing(rows, cols, nsmooth):
     """sizing of the `#define boxblur` mode of pffft_() -- Source.cpp:437-457"""
     out = (C.c_int * 4)()
@@ -233,8 +242,50 @@ class BlurContext:
         multiply, c2r, crop.  Inside the crop that is the linear convolution of the reflect-101 extended image with
         the same taps (every border is >= the kernel half width, so neither the wrap-around nor the extra
         transform-size padding reaches a kept pixel): the 1D-tiled engine computes it without materialising the
-        padded image.  tests/ compare with the scipy.fft (pocketfft) restatement of the 2D path."""
+        padded image.  tests/ compare with the scipy.fft (pocketfft) restatement of the 2D path.
+
+        whole_image=True runs the reference's own structure instead (blur_pocketfft2d_u8c3_dev: the padded image as
+        ONE 2D transform with pocketfft_2D's sizes and borders); want_planes=True then also returns the float planes
+        [3, rows, cols] before the "+0.5f, truncate"."""
+        if kw.pop("whole_image", False):
+            return self._pocketfft2d(image, sigma, out, 0, kw.pop("want_planes", False))
         return self.pffft_(image, sigma, out=out, nyquist_quirk=False, **kw)
+
+    def DFT_image(self, image, sigma, out=None, want_planes=False):
+        """pocketfft_2D compiled with `#define DFT_image` (Source.cpp:235-252): every plane becomes the fft-shifted
+        log spectrum 20 log10(|Re F| + 1e-5) of the reflect-101 padded plane (sigma only sets the padding), read with
+        the reference's index arithmetic, interleaved ("+0.5f, truncate") and cropped like the blur."""
+        return self._pocketfft2d(image, sigma, out, 1, want_planes)
+
+    def _pocketfft2d(self, image, sigma, out, dft_image, want_planes):
+        if isinstance(image, np.ndarray):                       # host round trip, returns a new array
+            a = np.ascontiguousarray(image, np.uint8)
+            if a.ndim != 3 or a.shape[2] != 3 or want_planes:
+                raise ValueError("expected a uint8 image [rows, cols, 3] (float planes: device tensors only)")
+            res = np.empty_like(a)
+            self._check(self._lib.blur_pocketfft2d_u8c3_host(self._h, a.ctypes.data, res.ctypes.data, a.shape[0], a.shape[1], float(sigma), int(dft_image)))
+            return res
+        import torch
+        if image.dtype != torch.uint8 or not image.is_cuda or not image.is_contiguous() or image.dim() != 3 or image.shape[-1] != 3:
+            raise ValueError("expected a contiguous CUDA uint8 tensor [rows, cols, 3]")
+        dst = image if out is None else out
+        planes = torch.empty((3, image.shape[0], image.shape[1]), dtype=torch.float32, device=image.device) if want_planes else None
+        self.use_torch_stream()
+        self._check(self._lib.blur_pocketfft2d_u8c3_dev(self._h, image.data_ptr(), dst.data_ptr(), image.shape[0], image.shape[1], float(sigma),
+                                                        int(dft_image), planes.data_ptr() if want_planes else None))
+        return (dst, planes) if want_planes else dst
+
+    def Reflect_101(self, image, top, bottom, left, right):
+        """Reflect_101<uint8_t, C> (Utils.hpp:212-243): uint8 CUDA tensor [rows, cols, C] -> padded tensor; borders are
+        clamped to dim - 1 like the reference"""
+        import torch
+        rows, cols, ch = image.shape
+        size = (C.c_int * 2)()
+        self._check(self._lib.blur_reflect101_u8_dev(self._h, None, None, rows, cols, ch, int(top), int(bottom), int(left), int(right), size))
+        out = torch.empty((size[0], size[1], ch), dtype=torch.uint8, device=image.device)
+        self.use_torch_stream()
+        self._check(self._lib.blur_reflect101_u8_dev(self._h, image.data_ptr(), out.data_ptr(), rows, cols, ch, int(top), int(bottom), int(left), int(right), size))
+        return out
 
     def pffft_boxblur(self, image, nsmooth, out=None, nyquist_quirk=True):
         """pffft_() compiled with `#define boxblur`: FFT-domain tent kernel (Source.cpp:437-442,468-472);

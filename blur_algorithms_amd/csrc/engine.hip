@@ -462,6 +462,126 @@ __global__ __launch_bounds__(256) void boxrow4_kernel(const uint8_t* __restrict_
     }
 }
 
+
+// ------------------------------------------------------------------------------------
+// Whole-image 2D transform path: pocketfft_2D (Source.cpp:143-277) and its DFT_image branch (:235-252).
+//
+// The padded image (Reflect_101 on all four sides, :178-180) is transformed as ONE 2D FFT.  Two colour planes ride in
+// one complex image z = a + i b (the kernel spectrum is real, so they never mix in the blur; for the spectrum image
+// they are separated with F_a[k] = (Z[k] + conj Z[-k]) / 2).  Spectra stay in the position order of the plans along
+// both axes; nothing is reordered in memory.
+//
+//   img2d_rows_fwd   u8 image -> z rows: reflect-101 + deinterleave + pack fused into the load, forward FFT along x
+//   img2d_cols<true> strip of G columns: (x Krow[pos_x]) -> forward along y -> x Kcol[pos_y] -> inverse along y  (:255-260)
+//   img2d_cols<false>                    forward along y only (DFT_image keeps the spectrum)
+//   img2d_rows_inv   rows of the crop: inverse along x, "+0.5f, truncate", crop (:263-276) -> u8 image
+//   img2d_logspec    fftshift + 20 log10(|Re F| + 1e-5) with the reference's index arithmetic (:238-251), crop
+// ------------------------------------------------------------------------------------
+struct Img2dGeom { int rows, cols, s0, s1, top, left; };
+
+__global__ __launch_bounds__(256) void img2d_rows_fwd_kernel(const uint8_t* __restrict__ src, float2* __restrict__ z, Img2dGeom g, int ca, int cb,
+                                                             DevPlan plan, const float2* __restrict__ tw)
+{
+    extern __shared__ float2 lds2d[];
+    const int zs = line_stride(plan.n);
+    const int y = blockIdx.x;
+    const uint8_t* row = src + static_cast<size_t>(refl101(y - g.top, g.rows)) * g.cols * 3;
+    for (int x = threadIdx.x; x < g.s1; x += blockDim.x) {
+        const uint8_t* px = row + 3 * refl101(x - g.left, g.cols);
+        lds2d[phys(x)] = make_float2(static_cast<float>(px[ca]), cb >= 0 ? static_cast<float>(px[cb]) : 0.f);
+    }
+    __syncthreads();
+    fft_forward_lines<1>(lds2d, zs, plan, tw);
+    float2* out = z + static_cast<size_t>(y) * g.s1;
+    for (int pos = threadIdx.x; pos < g.s1; pos += blockDim.x) out[pos] = lds2d[phys(pos)];
+}
+
+template <int G, bool CONV>
+__global__ __launch_bounds__(256) void img2d_cols_kernel(float2* __restrict__ z, int s0, int s1, DevPlan plan, const float2* __restrict__ tw,
+                                                         const float* __restrict__ mcol, const float* __restrict__ krow_pos)
+{
+    extern __shared__ float2 lds2d[];
+    const int zs = line_stride(plan.n);
+    const int x0 = blockIdx.x * G;
+    for (int idx = threadIdx.x; idx < s0 * G; idx += blockDim.x) {
+        const int y = idx / G, c = idx - y * G, x = x0 + c;
+        float2 v = make_float2(0.f, 0.f);
+        if (x < s1) {
+            v = z[static_cast<size_t>(y) * s1 + x];
+            if (CONV) v = cscale(v, krow_pos[x]);
+        }
+        lds2d[c * zs + phys(y)] = v;
+    }
+    __syncthreads();
+    if (CONV) fftconv_lines<G>(lds2d, zs, plan, tw, mcol);
+    else fft_forward_lines<G>(lds2d, zs, plan, tw);
+    for (int idx = threadIdx.x; idx < s0 * G; idx += blockDim.x) {
+        const int y = idx / G, c = idx - y * G, x = x0 + c;
+        if (x < s1) z[static_cast<size_t>(y) * s1 + x] = lds2d[c * zs + phys(y)];
+    }
+}
+
+__global__ __launch_bounds__(256) void img2d_rows_inv_kernel(const float2* __restrict__ z, uint8_t* __restrict__ dst, float* __restrict__ planes, Img2dGeom g,
+                                                             int ca, int cb, DevPlan plan, const float2* __restrict__ tw)
+{
+    extern __shared__ float2 lds2d[];
+    const int zs = line_stride(plan.n);
+    const int i = blockIdx.x;                                   // row of the cropped image
+    const float2* in = z + static_cast<size_t>(i + g.top) * g.s1;
+    for (int pos = threadIdx.x; pos < g.s1; pos += blockDim.x) lds2d[phys(pos)] = in[pos];
+    __syncthreads();
+    fft_inverse_lines<1>(lds2d, zs, plan, tw);
+    const size_t plane = static_cast<size_t>(g.rows) * g.cols;
+    for (int j = threadIdx.x; j < g.cols; j += blockDim.x) {
+        const float2 v = lds2d[phys(j + g.left)];
+        const size_t px = static_cast<size_t>(i) * g.cols + j;
+        dst[3 * px + ca] = static_cast<uint8_t>(static_cast<int>(v.x + 0.5f));
+        if (cb >= 0) dst[3 * px + cb] = static_cast<uint8_t>(static_cast<int>(v.y + 0.5f));
+        if (planes) {
+            planes[ca * plane + px] = v.x;
+            if (cb >= 0) planes[cb * plane + px] = v.y;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void img2d_logspec_kernel(const float2* __restrict__ z, uint8_t* __restrict__ dst, float* __restrict__ planes, Img2dGeom g,
+                                                            int ca, int cb, const int* __restrict__ pos_of_freq_y, const int* __restrict__ pos_of_freq_x)
+{
+    const size_t plane = static_cast<size_t>(g.rows) * g.cols;
+    for (size_t px = blockIdx.x * 256u + threadIdx.x; px < plane; px += static_cast<size_t>(gridDim.x) * 256u) {
+        const int i = static_cast<int>(px / g.cols), j = static_cast<int>(px - static_cast<size_t>(i) * g.cols);
+        const int row = i + g.top, col = j + g.left;
+        // FFTSHIFT, "odd/even treated as in matlab" (Source.cpp:239-241)
+        const int fy = (row + (g.s0 % 2 == 0 ? g.s0 : g.s0 + 1) / 2) % g.s0;
+        const int col_ = (col + (g.s1 % 2 == 0 ? g.s1 : g.s1 + 1) / 2) % g.s1;
+        // "Reverse reading from end to the beginning after reached (sizes[1] / 2 + 1)" (:243): the reference indexes
+        // its HALF spectrum, so the right half shows column s1/2 - col_ % (s1/2) of the SAME row
+        const int fx = col_ < g.s1 / 2 + 1 ? col_ : g.s1 / 2 - col_ % (g.s1 / 2);
+        const float2 p = z[static_cast<size_t>(pos_of_freq_y[fy]) * g.s1 + pos_of_freq_x[fx]];
+        const float2 q = z[static_cast<size_t>(pos_of_freq_y[(g.s0 - fy) % g.s0]) * g.s1 + pos_of_freq_x[(g.s1 - fx) % g.s1]];
+        const float va = 20.f * log10f(fabsf(0.5f * (p.x + q.x)) + 0.00001f);
+        dst[3 * px + ca] = static_cast<uint8_t>(static_cast<int>(va + 0.5f));
+        if (planes) planes[ca * plane + px] = va;
+        if (cb >= 0) {
+            const float vb = 20.f * log10f(fabsf(0.5f * (p.y + q.y)) + 0.00001f);
+            dst[3 * px + cb] = static_cast<uint8_t>(static_cast<int>(vb + 0.5f));
+            if (planes) planes[cb * plane + px] = vb;
+        }
+    }
+}
+
+// Reflect_101<uint8_t, C> (Utils.hpp:212-243) as a piece: out[(rows+top+bottom) x (cols+left+right) x C]
+__global__ __launch_bounds__(256) void reflect101_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int rows, int cols, int C,
+                                                            int top, int left, int out_rows, int out_cols)
+{
+    const size_t total = static_cast<size_t>(out_rows) * out_cols;
+    for (size_t px = blockIdx.x * 256u + threadIdx.x; px < total; px += static_cast<size_t>(gridDim.x) * 256u) {
+        const int y = static_cast<int>(px / out_cols), x = static_cast<int>(px - static_cast<size_t>(y) * out_cols);
+        const uint8_t* s = in + (static_cast<size_t>(refl101(y - top, rows)) * cols + refl101(x - left, cols)) * C;
+        for (int c = 0; c < C; ++c) out[px * C + c] = s[c];
+    }
+}
+
 }  // namespace
 
 // ======================================================================================
@@ -473,6 +593,7 @@ struct DevicePlan {
     float2* d_tw = nullptr;
     const FastEntry* fast = nullptr;   // compile-time specialised kernels for this length, if any
     int key = 0;
+    int* d_pos_of_freq = nullptr;      // inverse of freq_of_pos, uploaded on first use (whole-image 2D path)
 };
 
 // staging for blur_gaussian_u8c3_host_batch: frame i+1 travels to the device and frame i-1 back to the host
@@ -506,7 +627,7 @@ struct blur_ctx {
     size_t work2_bytes = 0;
     uint8_t* box_tmp = nullptr;
     size_t box_bytes = 0;
-    int last_family = -1;         // kernels the last u8c3 blur used: 0 run-time plans, 1 specialised rows-first, 2 wave-resident
+    int last_family = -1;         // kernels the last u8c3 blur used: 0 run-time plans, 1 specialised rows-first, 2 wave-resident, 3 whole-image 2D
     void* host_stage = nullptr;   // device staging of the host-pointer entry points (kept between calls: no allocation per frame)
     size_t host_stage_bytes = 0;
     bool timing = false;
@@ -962,6 +1083,46 @@ static int run_colpass_u8c3(blur_ctx* ctx, const float* planes, uint8_t* dst, in
 // ======================================================================================
 // C ABI
 // ======================================================================================
+// ---- whole-image 2D path: helpers (the entry points are below, blur_pocketfft2d_*) ----
+static int get_pos_of_freq(blur_ctx* ctx, DevicePlan* dp, const int** out)
+{
+    if (!dp->d_pos_of_freq) {
+        const int n = dp->dev.n;
+        std::vector<int> inv(n);
+        for (int pos = 0; pos < n; ++pos) inv[dp->host.freq_of_pos[pos]] = pos;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dp->d_pos_of_freq), sizeof(int) * n));
+        HIP_TRY(ctx, hipMemcpy(dp->d_pos_of_freq, inv.data(), sizeof(int) * n, hipMemcpyHostToDevice));
+    }
+    *out = dp->d_pos_of_freq;
+    return BLUR_OK;
+}
+
+template <bool CONV>
+static int launch_img2d_cols(blur_ctx* ctx, float2* z, int s0, int s1, const DevicePlan& plan, const float* mcol, const float* krow_pos)
+{
+    // widest strip of columns whose lines fit the LDS: 8 columns = one 64-byte segment of a spectrum row
+    const size_t line = static_cast<size_t>(line_stride(s0)) * sizeof(float2);
+    int G = 8;
+    while (G > 1 && G * line > kLdsLimit) G >>= 1;
+    if (G * line > kLdsLimit) return fail(ctx, BLUR_ERR_UNSUPPORTED, "2D path: column FFT length exceeds LDS capacity");
+    const int grid = (s1 + G - 1) / G;
+#define BLUR_IMG2D_COLS(G_)                                                                                                        \
+    case G_:                                                                                                                        \
+        if (int rc = set_lds(ctx, img2d_cols_kernel<G_, CONV>, G_ * line)) return rc;                                              \
+        hipLaunchKernelGGL((img2d_cols_kernel<G_, CONV>), dim3(grid), dim3(kThreads), G_ * line, ctx->stream, z, s0, s1, plan.dev, \
+                           plan.d_tw, mcol, krow_pos);                                                                             \
+        break;
+    switch (G) {
+        BLUR_IMG2D_COLS(8)
+        BLUR_IMG2D_COLS(4)
+        BLUR_IMG2D_COLS(2)
+        BLUR_IMG2D_COLS(1)
+    }
+#undef BLUR_IMG2D_COLS
+    HIP_TRY(ctx, hipGetLastError());
+    return BLUR_OK;
+}
+
 extern "C" {
 
 void blur_opts_default(blur_opts* o)
@@ -1041,7 +1202,10 @@ int blur_ctx_destroy(blur_ctx* ctx)
     if (!ctx) return BLUR_ERR_INVALID;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (auto& kv : ctx->plans) if (kv.second->d_tw) (void)hipFree(kv.second->d_tw);
+    for (auto& kv : ctx->plans) {
+        if (kv.second->d_tw) (void)hipFree(kv.second->d_tw);
+        if (kv.second->d_pos_of_freq) (void)hipFree(kv.second->d_pos_of_freq);
+    }
     for (auto& kv : ctx->spectra) (void)hipFree(kv.second);
     if (ctx->d_w256) (void)hipFree(ctx->d_w256);
     for (auto& kv : ctx->wr_tw0) (void)hipFree(kv.second);
@@ -1330,6 +1494,111 @@ int blur_gaussian_f32c1_host(blur_ctx* ctx, const float* src, float* dst, int ro
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->err = std::string("host blur: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
     return rc;
+}
+
+// ---- whole-image 2D transform path (pocketfft_2D, Source.cpp:143-277) -----------------------------------------
+int blur_pocketfft2d_sizing(int rows, int cols, double sigma, int out[8])
+{
+    if (rows <= 0 || cols <= 0 || !(sigma > 0) || !out) return BLUR_ERR_INVALID;
+    const Sizing2D s = pocketfft2d_sizing(rows, cols, sigma);
+    const int v[8] = { s.kSize, s.pad, s.s0, s.s1, s.top, s.bottom, s.left, s.right };
+    std::memcpy(out, v, sizeof v);
+    return BLUR_OK;
+}
+
+int blur_pocketfft2d_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int rows, int cols, double sigma, int dft_image, float* d_planes)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!d_src || !d_dst) return fail(ctx, BLUR_ERR_INVALID, "null image pointer");
+    if (rows <= 0 || cols <= 0 || !(sigma > 0)) return fail(ctx, BLUR_ERR_INVALID, "rows, cols and sigma must be positive");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const Sizing2D sz = pocketfft2d_sizing(rows, cols, sigma);
+    // Reflect_101 clamps a border to dim - 1 (Utils.hpp:217-220) while pocketfft_2D keeps its own sizes[]: past that
+    // point the reference's buffers no longer agree with each other
+    if (std::max(sz.top, sz.bottom) > rows - 1 || std::max(sz.left, sz.right) > cols - 1)
+        return fail(ctx, BLUR_ERR_UNSUPPORTED, "2D path: border > dim - 1 (Reflect_101 would clamp it, Utils.hpp:217-220)");
+    if (static_cast<long long>(sz.s0) * sz.s1 > (1ll << 31) - 1) return fail(ctx, BLUR_ERR_UNSUPPORTED, "2D path: ndata exceeds int (Source.cpp:230)");
+    DevicePlan *prow = nullptr, *pcol = nullptr;
+    if (int rc = get_plan(ctx, sz.s1, false, false, &prow)) return rc;
+    if (int rc = get_plan(ctx, sz.s0, false, true, &pcol)) return rc;
+    const size_t row_lds = row_lds_bytes(sz.s1);
+    if (row_lds > kLdsLimit) return fail(ctx, BLUR_ERR_UNSUPPORTED, "2D path: row FFT length exceeds LDS capacity");
+    float *mrow = nullptr, *mcol = nullptr;
+    const int *pofy = nullptr, *pofx = nullptr;
+    if (dft_image) {
+        if (int rc = get_pos_of_freq(ctx, pcol, &pofy)) return rc;
+        if (int rc = get_pos_of_freq(ctx, prow, &pofx)) return rc;
+    } else {
+        // Re(kerf_1D_row[j]) * Re(kerf_1D_col[i]) * (1 / ndata) (:255-263) as two tables in position order, each
+        // carrying the 1/n of its own axis; the mirrored upper half of kerf_1D_col (:207) is min(f, n - f) of the table
+        if (int rc = get_spectrum(ctx, *prow, sigma, sz.kSize, false, &mrow)) return rc;
+        if (int rc = get_spectrum(ctx, *pcol, sigma, sz.kSize, false, &mcol)) return rc;
+    }
+    if (int rc = ensure_work(ctx, static_cast<size_t>(sz.s0) * sz.s1 * sizeof(float2))) return rc;
+    float2* z = reinterpret_cast<float2*>(ctx->work);
+    if (int rc = set_lds(ctx, img2d_rows_fwd_kernel, row_lds)) return rc;
+    if (int rc = set_lds(ctx, img2d_rows_inv_kernel, row_lds)) return rc;
+    const Img2dGeom g{ rows, cols, sz.s0, sz.s1, sz.top, sz.left };
+    ctx->last_family = 3;
+    const int pairs[2][2] = { { 0, 1 }, { 2, -1 } };
+    for (const auto& pr : pairs) {
+        hipLaunchKernelGGL(img2d_rows_fwd_kernel, dim3(sz.s0), dim3(kThreads), row_lds, ctx->stream, d_src, z, g, pr[0], pr[1], prow->dev, prow->d_tw);
+        HIP_TRY(ctx, hipGetLastError());
+        if (dft_image) {
+            if (int rc = launch_img2d_cols<false>(ctx, z, sz.s0, sz.s1, *pcol, nullptr, nullptr)) return rc;
+            const size_t px = static_cast<size_t>(rows) * cols;
+            const int grid = static_cast<int>(std::min<size_t>((px + 255) / 256, static_cast<size_t>(ctx->num_cus) * 16));
+            hipLaunchKernelGGL(img2d_logspec_kernel, dim3(grid), dim3(256), 0, ctx->stream, z, d_dst, d_planes, g, pr[0], pr[1], pofy, pofx);
+        } else {
+            if (int rc = launch_img2d_cols<true>(ctx, z, sz.s0, sz.s1, *pcol, mcol, mrow)) return rc;
+            hipLaunchKernelGGL(img2d_rows_inv_kernel, dim3(rows), dim3(kThreads), row_lds, ctx->stream, z, d_dst, d_planes, g, pr[0], pr[1], prow->dev, prow->d_tw);
+        }
+        HIP_TRY(ctx, hipGetLastError());
+    }
+    return BLUR_OK;
+}
+
+int blur_pocketfft2d_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int rows, int cols, double sigma, int dft_image)
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (!src || !dst || rows <= 0 || cols <= 0) return fail(ctx, BLUR_ERR_INVALID, "null image or non-positive size");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = static_cast<size_t>(rows) * cols * 3;
+    void* dv = nullptr;
+    if (int rc0 = ensure_host_stage(ctx, bytes, &dv)) return rc0;
+    uint8_t* d = static_cast<uint8_t*>(dv);
+    int rc = BLUR_OK;
+    hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream);
+    // in place on the device, like the reference (image.data is source and destination): the pass over planes 0 and 1
+    // writes only their bytes, and the later pass over plane 2 reads only plane 2
+    if (e == hipSuccess) rc = blur_pocketfft2d_u8c3_dev(ctx, d, d, rows, cols, sigma, dft_image, nullptr);
+    if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->err = std::string("host 2D path: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
+    return rc;
+}
+
+int blur_reflect101_u8_dev(blur_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, int rows, int cols, int channels, int top, int bottom, int left, int right,
+                           int out_size[2])
+{
+    if (!ctx) return BLUR_ERR_INVALID;
+    if (rows <= 0 || cols <= 0 || channels <= 0 || top < 0 || bottom < 0 || left < 0 || right < 0)
+        return fail(ctx, BLUR_ERR_INVALID, "Reflect_101: bad arguments");
+    // the reference's only difference to cv::copyMakeBorder: borders are clamped to dim - 1 (Utils.hpp:217-220)
+    top = std::min(top, rows - 1);
+    bottom = std::min(bottom, rows - 1);
+    left = std::min(left, cols - 1);
+    right = std::min(right, cols - 1);
+    const int orows = rows + top + bottom, ocols = cols + left + right;
+    if (out_size) { out_size[0] = orows; out_size[1] = ocols; }
+    if (!d_out) return BLUR_OK;                                  // size query
+    if (!d_in || d_in == d_out) return fail(ctx, BLUR_ERR_INVALID, "Reflect_101: null input or in place");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t px = static_cast<size_t>(orows) * ocols;
+    const int grid = static_cast<int>(std::min<size_t>((px + 255) / 256, static_cast<size_t>(ctx->num_cus) * 16));
+    hipLaunchKernelGGL(reflect101_u8_kernel, dim3(grid), dim3(256), 0, ctx->stream, d_in, d_out, rows, cols, channels, top, left, orows, ocols);
+    HIP_TRY(ctx, hipGetLastError());
+    return BLUR_OK;
 }
 
 int blur_flip_block_f32_dev(blur_ctx* ctx, const float* d_in, float* d_out, int w, int h)

@@ -278,14 +278,36 @@ template <int R, int C> BLUR_HD void pass_mid(float2* z, int zs, int n, const fl
     }
 }
 
-enum PassKind { kFwd = 0, kMid = 1, kInv = 2 };
+// a pass with m == 1 on its own (no twiddles, no multiply): the last forward or the first inverse pass of a transform
+// that is NOT fused with a pointwise multiply (the whole-image 2D path, Source.cpp:233, keeps its spectrum)
+template <int R, int C, bool INV> BLUR_HD void pass_plain(float2* z, int zs, int n, int tid, int nthreads)
+{
+    const int nb = n / R;
+    for (int g = tid; g < nb; g += nthreads) {
+        const int base = g * R;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            float2* zc = z + c * zs;
+            float2 v[R];
+#pragma unroll
+            for (int k = 0; k < R; ++k) v[k] = zc[phys(base + k)];
+            Bfly<R, INV>::run(v);
+#pragma unroll
+            for (int k = 0; k < R; ++k) zc[phys(base + k)] = v[k];
+        }
+    }
+}
+
+enum PassKind { kFwd = 0, kMid = 1, kInv = 2, kFwdLast = 3, kInvFirst = 4 };
 
 template <int R, int C>
 BLUR_HD void run_pass_r(int kind, float2* z, int zs, int n, int m, const float2* tw, const float* mperm, int tid, int nthreads)
 {
     if (kind == kFwd) pass_fwd<R, C>(z, zs, n, m, tw, tid, nthreads);
     else if (kind == kInv) pass_inv<R, C>(z, zs, n, m, tw, tid, nthreads);
-    else pass_mid<R, C>(z, zs, n, mperm, tid, nthreads);
+    else if (kind == kMid) pass_mid<R, C>(z, zs, n, mperm, tid, nthreads);
+    else if (kind == kFwdLast) pass_plain<R, C, false>(z, zs, n, tid, nthreads);
+    else pass_plain<R, C, true>(z, zs, n, tid, nthreads);
 }
 
 // one pass of the plan for thread `tid`; the caller synchronises between passes
@@ -334,6 +356,27 @@ __device__ __forceinline__ void fftconv_lines(float2* z, int zs, const DevPlan& 
         int kind, i;
         schedule_step(p, s, kind, i);
         run_pass<C>(kind, p.radix[i], z, zs, p.n, p.m[i], tw + p.tw_off[i], mperm, threadIdx.x, blockDim.x);
+        __syncthreads();
+    }
+}
+
+// forward FFT only of C lines in LDS; the spectrum stays in position order (frequency freq_of_pos[pos] at
+// position pos).  Ends with a barrier.
+template <int C>
+__device__ __forceinline__ void fft_forward_lines(float2* z, int zs, const DevPlan& p, const float2* tw)
+{
+    for (int i = 0; i < p.npass; ++i) {
+        run_pass<C>(i == p.npass - 1 ? kFwdLast : kFwd, p.radix[i], z, zs, p.n, p.m[i], tw + p.tw_off[i], nullptr, threadIdx.x, blockDim.x);
+        __syncthreads();
+    }
+}
+
+// inverse FFT only (unnormalised) of C spectra held in position order.  Ends with a barrier.
+template <int C>
+__device__ __forceinline__ void fft_inverse_lines(float2* z, int zs, const DevPlan& p, const float2* tw)
+{
+    for (int i = p.npass - 1; i >= 0; --i) {
+        run_pass<C>(i == p.npass - 1 ? kInvFirst : kInv, p.radix[i], z, zs, p.n, p.m[i], tw + p.tw_off[i], nullptr, threadIdx.x, blockDim.x);
         __syncthreads();
     }
 }

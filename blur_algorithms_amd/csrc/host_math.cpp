@@ -79,6 +79,31 @@ Sizing pffft_sizing(int rows, int cols, double sigma)
     return s;
 }
 
+Sizing2D pocketfft2d_sizing(int rows, int cols, double sigma)
+{
+    Sizing2D s{};
+    s.kSize = gaussian_window(sigma, std::max(rows, cols));
+    s.pad = (s.kSize - 1) / 2;
+    int border[4] = { s.pad, s.pad, s.pad, s.pad };
+    int sizes[2] = { rows + 2 * s.pad, cols + 2 * s.pad };
+    for (int i = 0; i < 2; ++i)
+        if (!is_valid_size(sizes[i])) {
+            const int grown = nearest_transform_size(sizes[i]);
+            const int extra = grown - sizes[i];
+            sizes[i] = grown;
+            border[2 * i] += extra / 2;
+            // the reference adds a float to the int (`border += new_pad / 2.f + 0.5f`): int -> float, add, truncate
+            border[2 * i + 1] = static_cast<int>(static_cast<float>(border[2 * i + 1]) + (extra / 2.f + 0.5f));
+        }
+    s.s0 = sizes[0];
+    s.s1 = sizes[1];
+    s.top = border[0];
+    s.bottom = border[1];
+    s.left = border[2];
+    s.right = border[3];
+    return s;
+}
+
 void kernel_multipliers(double sigma, int ksize, int n, float* m)
 {
     std::vector<float> k(std::max(n, ksize));

@@ -24,6 +24,15 @@ struct Sizing {
 // Source.cpp:434-457
 Sizing pffft_sizing(int rows, int cols, double sigma);
 
+// pocketfft_2D's sizing, Source.cpp:149-176: one reflect-101 border per side; when a padded side is not 2^a 3^b 5^c the
+// extra goes into the borders of that axis (floor before, ceil after), not into trailing zeros as in pffft_()
+struct Sizing2D {
+    int kSize, pad;
+    int s0, s1;                       // sizes[0] (rows + top + bottom), sizes[1] (cols + left + right)
+    int top, bottom, left, right;     // border[0..3]
+};
+Sizing2D pocketfft2d_sizing(int rows, int cols, double sigma);
+
 // m[b] = float(Re DFT(kernel)[b]) * (1.f / n), b = 0..n/2   (Source.cpp:423,506-507)
 void kernel_multipliers(double sigma, int ksize, int n, float* m);
 

@@ -164,7 +164,33 @@ int blur_boxfft_sizing(int rows, int cols, double nsmooth, int out[4]);
 /* box_kernel(kernel, kLen, FFT_length), 1D form: fft_length floats (host)  Source.cpp:129-140 */
 int blur_box_kernel(float* kernel, int klen, int fft_length);
 
+/* ---- pocketfft_2D: the whole padded image as ONE 2D transform      Source.cpp:143-277 ---- */
+
+/* its sizing: out = { kSize, pad, sizes[0], sizes[1], border top, bottom, left, right }   Source.cpp:149-176
+   (extra padding for a 2^a 3^b 5^c side goes into the reflect-101 borders of that axis: floor before, ceil after) */
+int blur_pocketfft2d_sizing(int rows, int cols, double sigma, int out[8]);
+/* pocketfft_2D(image, sigma): Reflect_101 on four sides, deinterleave, r2c over both axes, multiply by
+   Re(kerf_1D_row[j]) Re(kerf_1D_col[i]), c2r with 1/ndata, interleave ("+0.5f, truncate"), crop   (:178-276).
+   dft_image != 0 builds the `#define DFT_image` variant instead (:235-252): every plane of the result is the
+   fft-shifted log spectrum 20 log10(|Re F| + 1e-5) of the padded plane, read with the reference's index arithmetic,
+   then interleaved and cropped like the blur.  d_planes (optional, may be NULL): the cropped float planes
+   [3][rows][cols] before the "+0.5f, truncate".  d_dst may equal d_src.  Asynchronous on the context's stream.
+   In exact arithmetic the blur equals blur_gaussian_u8c3_dev with nyquist_quirk = 0, which is several times faster
+   (two fused kernels instead of six); this entry point exists for the spectrum image and for callers who want the
+   reference's 2D structure (its sizes and borders) reproduced step by step.
+   BLUR_ERR_UNSUPPORTED when a border exceeds dim - 1 (Reflect_101 clamps there, Utils.hpp:217-220, and the
+   reference's own buffers stop agreeing) or a side does not fit the LDS (about 19000). */
+int blur_pocketfft2d_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int rows, int cols, double sigma,
+                              int dft_image, float* d_planes);
+int blur_pocketfft2d_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int rows, int cols, double sigma, int dft_image);
+
 /* ---- the pieces either side of it -------------------------------------------------- */
+
+/* Reflect_101<uint8_t, C>(input, output, top, bottom, left, right, original_size)       Utils.hpp:212-243
+   borders are clamped to dim - 1 like the reference; out_size = { rows + top + bottom, cols + left + right } after the
+   clamp (d_out == NULL: size query only).  Out of place. */
+int blur_reflect101_u8_dev(blur_ctx* ctx, const uint8_t* d_in, uint8_t* d_out, int rows, int cols, int channels,
+                           int top, int bottom, int left, int right, int out_size[2]);
 
 /* flip_block<float,1>(in, out, w, h): out[x*h+y] = in[y*w+x]     call sites Source.cpp:540,562 */
 int blur_flip_block_f32_dev(blur_ctx* ctx, const float* d_in, float* d_out, int w, int h);

@@ -15,7 +15,8 @@
 //   flip_block<T,C>(in, out, w, h)                          call sites Source.cpp:540,562
 //   fastboxblur(in, w, h, channels, ksize, passes)          call site  Source.cpp:587
 //   pffft_(image, sigma)                                    Source.cpp:429-570
-//   pocketfft_1D(image, sigma) / pocketfft_2D(image, sigma) Source.cpp:280-392 / 143-277 (same engine, no Nyquist quirk)
+//   pocketfft_1D(image, sigma) / pocketfft_2D(image, sigma) Source.cpp:280-392 / 143-277 (same engine, no Nyquist quirk;
+//                                                           `#define DFT_image` -> the log-spectrum picture, :235-252)
 //
 // Everything lives in namespace blur_amd::compat; define BLUR_AMD_GLOBAL_NAMES before including
 // to also get the names in the global namespace, as the reference has them.
@@ -218,9 +219,26 @@ template <class Mat, class = decltype(std::declval<Mat&>().size[0])> void pocket
     o.nyquist_quirk = 0;
     pffft_(reinterpret_cast<uint8_t*>(image.data), static_cast<int>(image.size[0]), static_cast<int>(image.size[1]), nsmooth, nullptr, &o);
 }
+// The whole padded image as ONE 2D transform, with pocketfft_2D's own sizes and borders (blur_pocketfft2d_u8c3_host);
+// dft_image = the reference's `#define DFT_image` build (Source.cpp:235-252): the picture becomes the fft-shifted log
+// spectrum 20 log10(|Re F| + 1e-5) of every padded plane.
+inline void pocketfft_2D_whole(uint8_t* data, int rows, int cols, double sigma, bool dft_image = false, blur_ctx* ctx = nullptr)
+{
+    if (!ctx) ctx = default_ctx();
+    check(ctx, blur_pocketfft2d_u8c3_host(ctx, data, data, rows, cols, sigma, dft_image ? 1 : 0), "pocketfft_2D");
+}
+// pocketfft_2D(image, sigma).  Like the reference, the function follows the DFT_image macro of the translation unit
+// that includes this header; without it the blur runs on the (faster, equivalent) 1D-tiled engine, or on the
+// whole-image kernels when BLUR_AMD_POCKETFFT_2D_WHOLE_IMAGE is defined.
 template <class Mat, class = decltype(std::declval<Mat&>().size[0])> void pocketfft_2D(Mat& image, double nsmooth)
 {
+#if defined(DFT_image)
+    pocketfft_2D_whole(reinterpret_cast<uint8_t*>(image.data), static_cast<int>(image.size[0]), static_cast<int>(image.size[1]), nsmooth, true);
+#elif defined(BLUR_AMD_POCKETFFT_2D_WHOLE_IMAGE)
+    pocketfft_2D_whole(reinterpret_cast<uint8_t*>(image.data), static_cast<int>(image.size[0]), static_cast<int>(image.size[1]), nsmooth, false);
+#else
     pocketfft_1D(image, nsmooth);
+#endif
 }
 
 // ---- image in / out (the role cv::imread / cv::imwrite play in main(), Source.cpp:623,635) ----------------------
@@ -294,5 +312,6 @@ using blur_amd::compat::nearestTransformSize;
 using blur_amd::compat::pffft_;
 using blur_amd::compat::pocketfft_1D;
 using blur_amd::compat::pocketfft_2D;
+using blur_amd::compat::pocketfft_2D_whole;
 using blur_amd::compat::Reflect_101;
 #endif

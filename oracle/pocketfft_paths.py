@@ -11,6 +11,7 @@ does not depend on this repo's own FFT restatement.
     pocketfft_1d_u8c3   Source.cpp:280-392   1D tiles, same structure as pffft_() but N/2+1 bins
                                              with the true Nyquist multiplier (:362,:378)
     pocketfft_2d_u8c3   Source.cpp:143-277   whole padded image, r2c over both axes, crop (:268-276)
+    dft_image_u8c3      Source.cpp:235-252   the same function compiled with `#define DFT_image`: log spectrum image
 
 Both equal, in exact arithmetic, a linear convolution of the reflect-101 extended image inside the
 cropped region, which is also what pffft_() computes apart from its Nyquist-slot quirk
@@ -84,22 +85,28 @@ def pocketfft_1d_u8c3(img, sigma, dtype=np.float32, want_planes=False):
     return (u8, out.astype(np.float32)) if want_planes else u8
 
 
-def pocketfft_2d_u8c3(img, sigma, dtype=np.float32, want_planes=False):
-    """pocketfft_2D(image, sigma), Source.cpp:143-277 (Gaussian build, without DFT_image)"""
-    a = np.ascontiguousarray(img, np.uint8)
-    rows, cols, ch = a.shape
-    assert ch == 3
+def _sizes_2d(rows, cols, sigma):
+    """Source.cpp:149-176 -> ksize, pad, sizes, border (top, bottom, left, right)"""
     ksize = O.gaussian_window(sigma, max(rows, cols))
     pad = (ksize - 1) // 2
-    border = [pad, pad, pad, pad]                                     # top, bottom, left, right (:159)
+    border = [pad, pad, pad, pad]
     sizes = [rows + 2 * pad, cols + 2 * pad]
-    for i in range(2):                                                # (:165-175)
+    for i in range(2):
         if not O.is_valid_size(sizes[i]):
             n = O.nearest_transform_size(sizes[i])
             new_pad = n - sizes[i]
             sizes[i] = n
             border[2 * i] += new_pad // 2
             border[2 * i + 1] = int(np.float32(border[2 * i + 1]) + np.float32(new_pad) / np.float32(2) + np.float32(0.5))
+    return ksize, pad, sizes, border
+
+
+def pocketfft_2d_u8c3(img, sigma, dtype=np.float32, want_planes=False):
+    """pocketfft_2D(image, sigma), Source.cpp:143-277 (Gaussian build, without DFT_image)"""
+    a = np.ascontiguousarray(img, np.uint8)
+    rows, cols, ch = a.shape
+    assert ch == 3
+    ksize, pad, sizes, border = _sizes_2d(rows, cols, sigma)         # (:149-176)
     if max(border[0], border[1]) > rows - 1 or max(border[2], border[3]) > cols - 1:
         raise ValueError("border > dim - 1: Reflect_101 would clamp it and the reference's buffers no longer match")
     padded = O.reflect_101(a, *border)                                # (:178-180)
@@ -119,3 +126,41 @@ def pocketfft_2d_u8c3(img, sigma, dtype=np.float32, want_planes=False):
     crop = (slice(border[0], sizes[0] - border[1]), slice(border[2], sizes[1] - border[3]))
     res = np.ascontiguousarray(u8[crop])                              # (:271-276)
     return (res, np.ascontiguousarray(out[:, crop[0], crop[1]]).astype(np.float32)) if want_planes else res
+
+
+def dft_image_u8c3(img, sigma, dtype=np.float32):
+    """pocketfft_2D(image, sigma) compiled with `#define DFT_image` (Source.cpp:235-252): instead of the multiply and
+    the inverse transform, every padded plane is overwritten with 20 log10(|Re resf| + 1e-5) read through the
+    reference's fftshift index arithmetic (:239-244, which mirrors the COLUMN index only into the half spectrum);
+    interleave_BGR and the crop follow as in the blur.
+
+    Returns (u8 image [rows, cols, 3], float planes [3, rows, cols], |Re F| planes [3, rows, cols]); the last one lets
+    a test tell the pixels whose logarithm is well conditioned (|Re F| far above the transform's rounding noise)
+    from those that are rounding noise in ANY float32 FFT, the reference's included.  The u8 conversion is C's
+    float -> int -> uint8_t (Utils.hpp:189,204-206): values below zero wrap modulo 256."""
+    a = np.ascontiguousarray(img, np.uint8)
+    rows, cols, ch = a.shape
+    assert ch == 3
+    _, _, sizes, border = _sizes_2d(rows, cols, sigma)
+    if max(border[0], border[1]) > rows - 1 or max(border[2], border[3]) > cols - 1:
+        raise ValueError("border > dim - 1")
+    s0, s1 = sizes
+    padded = O.reflect_101(a, *border)
+    planes = np.moveaxis(padded, -1, 0).astype(dtype)
+    row = np.arange(s0)
+    col = np.arange(s1)
+    row_ = (row + (s0 if s0 % 2 == 0 else s0 + 1) // 2) % s0                      # (:240)
+    col_ = (col + (s1 if s1 % 2 == 0 else s1 + 1) // 2) % s1                      # (:241)
+    cval = np.where(col_ < s1 // 2 + 1, col_, s1 // 2 - col_ % (s1 // 2))         # (:243)
+    logs = np.empty((3, s0, s1), np.float32)
+    mags = np.empty((3, s0, s1), np.float64)
+    for c in range(3):
+        resf = sfft.rfft2(planes[c])                                              # (:233)
+        re = np.real(resf)[row_[:, None], cval[None, :]]
+        mags[c] = np.abs(re)
+        logs[c] = (20 * np.log10(np.abs(re).astype(np.float32) + np.float32(0.00001))).astype(np.float32)   # (:245-248)
+    v = logs + np.float32(0.5)
+    u8 = np.moveaxis(np.trunc(v).astype(np.int64).astype(np.uint8), 0, -1)        # float -> int -> uint8_t
+    crop = (slice(border[0], s0 - border[1]), slice(border[2], s1 - border[3]))
+    return (np.ascontiguousarray(u8[crop]), np.ascontiguousarray(logs[:, crop[0], crop[1]]),
+            np.ascontiguousarray(mags[:, crop[0], crop[1]]))

@@ -118,6 +118,14 @@ int main(int argc, char** argv)
             std::ofstream(argv[6], std::ios::binary).write((const char*)img.data(), img.size());
             return 0;
         }
+        if ((mode == "whole2d" || mode == "dftimage") && argc == 7) {
+            std::vector<uint8_t> img = slurp(argv[2]);
+            const int rows = std::atoi(argv[3]), cols = std::atoi(argv[4]);
+            if (img.size() != (size_t)rows * cols * 3) { std::printf("bad input size\n"); return 2; }
+            pocketfft_2D_whole(img.data(), rows, cols, std::atof(argv[5]), mode == "dftimage");
+            std::ofstream(argv[6], std::ios::binary).write((const char*)img.data(), img.size());
+            return 0;
+        }
         if (mode == "box" && argc == 9) {
             std::vector<uint8_t> img = slurp(argv[2]);
             fastboxblur(img.data(), std::atoi(argv[3]), std::atoi(argv[4]), std::atoi(argv[5]), std::atoi(argv[6]), std::atoi(argv[7]));

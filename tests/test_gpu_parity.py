@@ -445,6 +445,9 @@ def test_cpp_surface_on_gpu(ctx, tmp_path):
     for mode in ("pocket1d", "pocket2d"):
         subprocess.check_call([exe, mode, str(tmp_path / "in.raw"), "96", "140", "6.0", str(tmp_path / "out.raw")])
         assert np.array_equal(np.frombuffer((tmp_path / "out.raw").read_bytes(), np.uint8).reshape(img.shape), want)
+    for mode, fn in (("whole2d", lambda t: ctx.pocketfft_2D(t, 6.0, whole_image=True)), ("dftimage", lambda t: ctx.DFT_image(t, 6.0))):
+        subprocess.check_call([exe, mode, str(tmp_path / "in.raw"), "96", "140", "6.0", str(tmp_path / "out.raw")])
+        assert np.array_equal(np.frombuffer((tmp_path / "out.raw").read_bytes(), np.uint8).reshape(img.shape), fn(torch.from_numpy(img).cuda()).cpu().numpy())
     subprocess.check_call([exe, "box", str(tmp_path / "in.raw"), "140", "96", "3", "9", "2", str(tmp_path / "box.raw")])
     got = np.frombuffer((tmp_path / "box.raw").read_bytes(), np.uint8).reshape(img.shape)
     from oracle import oracle as O

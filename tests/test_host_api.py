@@ -203,3 +203,42 @@ def test_example_main_compiles(tmp_path):
                            "-L" + os.path.dirname(B.LIB_PATH), "-lblur_amd", "-Wl,-rpath," + os.path.dirname(B.LIB_PATH),
                            "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
     assert subprocess.run([exe], capture_output=True).returncode == 2
+
+
+def test_pocketfft2d_sizing_matches_the_restatement():
+    """blur_pocketfft2d_sizing (Source.cpp:149-176) against oracle/pocketfft_paths._sizes_2d, including the float
+    arithmetic of `border += new_pad / 2.f + 0.5f` for odd extra padding"""
+    import itertools
+    from blur_algorithms_amd.api import pocketfft2d_sizing
+    from oracle import pocketfft_paths as P
+    odd_extra = 0
+    for r, c, s in itertools.product(range(20, 400, 37), range(25, 500, 41), (0.8, 2.0, 5.5, 13.0)):
+        k, p, sz, b = P._sizes_2d(r, c, s)
+        q = pocketfft2d_sizing(r, c, s)
+        assert (q["kSize"], q["pad"], list(q["sizes"]), list(q["border"])) == (k, p, sz, b)
+        assert sz[0] == r + b[0] + b[1] and sz[1] == c + b[2] + b[3]
+        odd_extra += (b[1] != b[0]) + (b[3] != b[2])
+    assert odd_extra > 10
+
+
+def test_dft_image_restatement_is_self_consistent():
+    """oracle/pocketfft_paths.dft_image_u8c3: DC at the fftshift centre, float32 and float64 transforms agree where the
+    logarithm is well conditioned, and the directly read half of every row is the plain fftshift of Re F"""
+    import scipy.fft as sfft
+    from oracle import oracle as O
+    from oracle import pocketfft_paths as P
+    img = np.random.default_rng(2).integers(0, 256, (90, 120, 3), dtype=np.uint8)
+    u8, l64, mags = P.dft_image_u8c3(img, 3.0, np.float64)
+    _, l32, _ = P.dft_image_u8c3(img, 3.0, np.float32)
+    ok = mags > 1e-5 * mags.max()
+    assert ok.mean() > 0.9 and np.abs(l32 - l64)[ok].max() < 0.01
+    _, _, sizes, border = P._sizes_2d(90, 120, 3.0)
+    i, j = np.unravel_index(np.argmax(l64[1]), l64[1].shape)
+    assert (i + border[0], j + border[2]) == (sizes[0] // 2, sizes[1] // 2)
+    padded = O.reflect_101(img, *border)
+    full = np.fft.fftshift(np.real(sfft.fft2(padded[..., 1].astype(np.float64))))
+    want = 20 * np.log10(np.abs(full) + 1e-5)[border[0]:sizes[0] - border[1], border[2]:sizes[1] - border[3]]
+    # fftshift puts frequency 0 at s1/2: displayed columns [s1/2, s1) hold frequencies 0..s1/2-1 (read directly),
+    # displayed columns [0, s1/2) hold negative frequencies, which the reference reads mirrored in the SAME row
+    direct = slice(sizes[1] // 2 - border[2], 120)
+    assert np.abs(l64[1][:, direct] - want[:, direct])[ok[1][:, direct]].max() < 1e-3
