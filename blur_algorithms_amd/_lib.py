@@ -70,6 +70,8 @@ SYMBOLS = {
     "blur_gaussian_u8c3_batch_multi_host": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),
     "blur_convolve_lines_c32_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, _P]),
     "blur_wr_length": (C.c_int, [C.c_int, C.c_int]),
+    "blur_mx_window_blocks": (C.c_int, [C.c_int]),
+    "blur_mx_fragments": (C.c_int, [_P, C.c_int, C.c_int, _P]),
     "blur_wr_kernel_multipliers": (C.c_int, [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "blur_malloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
     "blur_free": (C.c_int, [_P, _P]),

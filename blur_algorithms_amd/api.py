@@ -121,7 +121,7 @@ class BlurContext:
             raise BlurError(rc, self._lib.blur_last_error(self._h).decode())
 
     def _opts(self, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0, row_major_planes=False,
-              wave_resident=None):
+              wave_resident=None, engine=None):
         o = BlurOpts()
         self._lib.blur_opts_default(C.byref(o))
         o.nyquist_quirk = 1 if nyquist_quirk else 0
@@ -132,6 +132,10 @@ class BlurContext:
         # wave-resident kernels (transform length 256 * R0, columns first): None = where they pay (the image fills most
         # of the transform), False = never, True = wherever the image fits one
         o.reserved[3] = 0 if wave_resident is None else (2 if wave_resident else 1)
+        # engine: None = the library's choice; "matrix" = Toeplitz products on the f16 matrix cores (mx_kernels.hpp);
+        # "wave-resident" / "rows-first" = the two FFT kernel families
+        if engine is not None:
+            o.reserved[3] = {"matrix": 3, "wave-resident": 2, "rows-first": 1}[engine]
         return o
 
     def use_torch_stream(self):
@@ -156,13 +160,13 @@ class BlurContext:
 
     # -- pffft_(image, sigma): Source.cpp:429-570 -----------------------------------------
     def pffft_(self, image, sigma, out=None, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0,
-               row_major_planes=False, wave_resident=None):
+               row_major_planes=False, wave_resident=None, engine=None):
         """Gaussian blur of a BGR/RGB uint8 image [rows, cols, 3] or a batch [n, rows, cols, 3].
 
         torch CUDA tensor: asynchronous on torch's current stream, returns `out`
         (default: in place, like the reference).  numpy array: host round trip, returns a new array.
         """
-        o = self._opts(nyquist_quirk, col_group, force_generic, frames_per_launch, row_major_planes, wave_resident)
+        o = self._opts(nyquist_quirk, col_group, force_generic, frames_per_launch, row_major_planes, wave_resident, engine)
         if isinstance(image, np.ndarray):
             if (image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3 and not image.flags["C_CONTIGUOUS"]
                     and image.strides[2] == 1 and image.strides[1] == 3 and image.strides[0] >= 3 * image.shape[1]):

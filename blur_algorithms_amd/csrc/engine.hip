@@ -28,6 +28,8 @@
 #include "fast_registry.hpp"
 #include "fft_engine.hpp"
 #include "host_math.hpp"
+#define BLUR_MX_QUIRK_KERNELS
+#include "mx_registry.hpp"
 #include "wr_registry.hpp"
 
 using namespace blur_amd;
@@ -607,6 +609,14 @@ struct HostPipe {
     bool ready = false;
 };
 
+struct MxTables {
+    void* frags_row = nullptr;   // [2][nkb][64][8] binary16 (host_math.hpp: mx_fragments)
+    void* frags_col = nullptr;
+    float* taps_row = nullptr;   // 2 pad + 1 floats, centre at pad
+    float* taps_col = nullptr;
+    float dr = 0.f, dc = 0.f;    // m[0] - m[N/2] of the reference's row / column transform length (the quirk's gain)
+};
+
 struct blur_ctx {
     int device = 0;
     HostPipe pipe;
@@ -621,6 +631,12 @@ struct blur_ctx {
     float2* d_w256 = nullptr;
     std::map<int, float2*> wr_tw0;
     std::map<std::tuple<int, int, int, int, uint64_t>, float*> wr_spectra;   // (n, n_ref, ksize | -1, quirk, sigma bits | hash)
+    // matrix-core engine (mx_kernels.hpp): Toeplitz fragments + taps per kernel, integer sums and float terms of the quirk
+    std::map<std::tuple<int, int, int, uint64_t>, MxTables> mx_tables;   // (ksize | -1, n_row, n_col, sigma bits | hash); one nkb per pad
+    int* mx_sums = nullptr;
+    size_t mx_sums_bytes = 0;
+    float* mx_terms = nullptr;
+    size_t mx_terms_bytes = 0;
     float* work = nullptr;       // float planes of one frame
     size_t work_bytes = 0;
     float* work2 = nullptr;      // second set of planes: very tall images only (column pass without the LDS pixel stage)
@@ -869,6 +885,11 @@ struct Prepared {
     const WrEntry *wr_col = nullptr, *wr_row = nullptr;
     float2 *wr_tw0_col = nullptr, *wr_tw0_row = nullptr;
     float *wr_m_col = nullptr, *wr_m_row = nullptr;
+    // matrix-core kernels (both passes)
+    const MxEntry* mx = nullptr;
+    const MxTables* mxt = nullptr;
+    int mx_vpitch = 0;
+    bool mx_quirk = false;
 };
 
 // a caller-supplied separable kernel instead of the Gaussian: taps (odd count, centre in the middle)
@@ -928,6 +949,64 @@ static uint64_t fnv1a(const void* data, size_t bytes)
     return h;
 }
 
+// ---- matrix-core engine: tables ----------------------------------------------------------------------------------
+// taps of one axis from the reference's n-periodic kernel array (centre at index 0): taps[t + pad] = karr[(t + n) % n]
+static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz, const CustomKernel* ck, const MxTables** out)
+{
+    const int pad = sz.pad;
+    std::vector<float> karr[2];                                  // row axis (n_row), column axis (n_col)
+    const int nn[2] = { sz.n_row, sz.n_col };
+    uint64_t tag;
+    int kkey;
+    for (int ax = 0; ax < 2; ++ax) {
+        const int n = nn[ax];
+        if (ck) {
+            karr[ax].assign(n, 0.f);
+            if (ck->box_klen > 0) box_kernel_1d(karr[ax].data(), ck->box_klen, n);
+            else {
+                if (ck->ksize > n) return fail(ctx, BLUR_ERR_INVALID, "kernel longer than the padded line");
+                const int c = ck->ksize / 2;
+                for (int t = 0; t < ck->ksize; ++t) karr[ax][(t - c + n) % n] += ck->taps[t];
+            }
+        } else {
+            karr[ax].assign(std::max(n, sz.kSize), 0.f);
+            get_gaussian(karr[ax].data(), sigma, sz.kSize, n);    // Source.cpp:75-102
+        }
+    }
+    if (ck) { kkey = -1; tag = fnv1a(karr[0].data(), nn[0] * sizeof(float)) ^ (fnv1a(karr[1].data(), nn[1] * sizeof(float)) * 3); }
+    else { kkey = sz.kSize; std::memcpy(&tag, &sigma, sizeof tag); }
+    const auto key = std::make_tuple(kkey, nn[0], nn[1], tag);
+    auto it = ctx->mx_tables.find(key);
+    if (it != ctx->mx_tables.end()) { *out = &it->second; return BLUR_OK; }
+    MxTables t;
+    for (int ax = 0; ax < 2; ++ax) {
+        const int n = nn[ax];
+        std::vector<float> taps(2 * pad + 1);
+        for (int k = -pad; k <= pad; ++k) taps[k + pad] = karr[ax][(k + n) % n];
+        // anything of the kernel array outside +-pad would be lost here: the Toeplitz band is 2 pad + 1 wide
+        for (int i = pad + 1; i < n - pad; ++i)
+            if (karr[ax][i] != 0.f) return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: kernel wider than 2 pad + 1");
+        std::vector<uint16_t> fr(static_cast<size_t>(2) * nkb * 512);
+        mx_fragments(taps.data(), pad, nkb, fr.data());
+        // m[0] and m[n/2] as host_math's kernel_multipliers computes them: float(Re DFT) * (1.f / n)
+        long double k0 = 0, kalt = 0;
+        for (int i = 0; i < n; ++i) { k0 += karr[ax][i]; kalt += (i & 1) ? -static_cast<long double>(karr[ax][i]) : static_cast<long double>(karr[ax][i]); }
+        const float scaler = 1.f / n;
+        const float m0 = static_cast<float>(k0) * scaler, mh = static_cast<float>(kalt) * scaler;
+        void* dfr = nullptr;
+        float* dt = nullptr;
+        HIP_TRY(ctx, hipMalloc(&dfr, fr.size() * sizeof(uint16_t)));
+        HIP_TRY(ctx, hipMemcpy(dfr, fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dt), taps.size() * sizeof(float)));
+        HIP_TRY(ctx, hipMemcpy(dt, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
+        (ax ? t.frags_col : t.frags_row) = dfr;
+        (ax ? t.taps_col : t.taps_row) = dt;
+        (ax ? t.dc : t.dr) = m0 - mh;
+    }
+    *out = &(ctx->mx_tables[key] = t);
+    return BLUR_OK;
+}
+
 static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p, bool u8c3 = true,
                    const CustomKernel* ck = nullptr, bool allow_wr = true)
 {
@@ -948,6 +1027,20 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     const bool quirk = opts ? opts->nyquist_quirk != 0 : true;
     p.col_group = opts ? opts->col_group : 0;
     const bool allow_fast = u8c3 && !(opts && opts->reserved[0] == 1);   // reserved[0] = 1: force the generic kernels (tests)
+    // Matrix-core kernels (mx_kernels.hpp): reserved[3] = 3 asks for them
+    if (allow_fast && opts && opts->reserved[3] == 3) {
+        const MxEntry* me = find_mx_entry(p.sz.pad);
+        const int vpitch = (3 * cols + 31) & ~31;
+        if (!me) return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: no kernel instantiated for this pad");
+        if (static_cast<long long>(mx_vrows(rows, me->nkb)) * vpitch >= (1ll << 31) || static_cast<long long>(rows) * cols * 3 >= (1ll << 32))
+            return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: frame too large for 32-bit element offsets");
+        if (int rc = mx_get_tables(ctx, me->nkb, sigma, p.sz, ck, &p.mxt)) return rc;
+        p.mx = me;
+        p.mx_vpitch = vpitch;
+        p.mx_quirk = quirk;
+        p.frame_elems = static_cast<size_t>(mx_vrows(rows, me->nkb)) * vpitch;
+        return BLUR_OK;
+    }
     // Wave-resident kernels first (reserved[3] = 1 switches them off): both passes need one, and its LDS must hold the image
     if (allow_fast && allow_wr && !(opts && opts->reserved[3] == 1)) {
         const WrEntry* wc = find_wr_entry(rows + 2 * p.sz.pad, true);
@@ -1210,6 +1303,12 @@ int blur_ctx_destroy(blur_ctx* ctx)
     if (ctx->d_w256) (void)hipFree(ctx->d_w256);
     for (auto& kv : ctx->wr_tw0) (void)hipFree(kv.second);
     for (auto& kv : ctx->wr_spectra) (void)hipFree(kv.second);
+    for (auto& kv : ctx->mx_tables) {
+        (void)hipFree(kv.second.frags_row); (void)hipFree(kv.second.frags_col);
+        (void)hipFree(kv.second.taps_row); (void)hipFree(kv.second.taps_col);
+    }
+    if (ctx->mx_sums) (void)hipFree(ctx->mx_sums);
+    if (ctx->mx_terms) (void)hipFree(ctx->mx_terms);
     if (ctx->work) (void)hipFree(reinterpret_cast<char*>(ctx->work) - kWorkGuard);
     if (ctx->work2) (void)hipFree(ctx->work2);
     if (ctx->box_tmp) (void)hipFree(ctx->box_tmp);
@@ -1275,6 +1374,56 @@ int blur_ctx_timing(blur_ctx* ctx, double out_ms[2], int out_launches[2], int ou
     return BLUR_OK;
 }
 
+// both passes on the matrix cores; V (f32, row pitch a multiple of 32 floats) lives in the float workspace
+static int run_mx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes, int rows, int cols, int chunk, const Prepared& p)
+{
+    const size_t px = static_cast<size_t>(rows) * cols;
+    MxGeom g{ rows, cols, p.sz.pad, p.mx_vpitch, 0, 0, mx_vrows(rows, p.mx->nkb) };
+    const size_t sums_per_frame = (static_cast<size_t>(rows) + cols) * 3;                      // ints: Srow [rows][3], A [3 cols]
+    const int qpitch = 32 * ((rows + 31) / 32);
+    const size_t terms_per_frame = static_cast<size_t>(qpitch) * 3 + p.mx_vpitch;              // floats: qrow [3][qpitch], qcol [vpitch]
+    if (p.mx_quirk) {
+        if (ctx->mx_sums_bytes < sums_per_frame * chunk * sizeof(int)) {
+            if (ctx->mx_sums) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->mx_sums)); ctx->mx_sums = nullptr; ctx->mx_sums_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mx_sums), sums_per_frame * chunk * sizeof(int)));
+            ctx->mx_sums_bytes = sums_per_frame * chunk * sizeof(int);
+        }
+        if (ctx->mx_terms_bytes < terms_per_frame * chunk * sizeof(float)) {
+            if (ctx->mx_terms) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->mx_terms)); ctx->mx_terms = nullptr; ctx->mx_terms_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mx_terms), terms_per_frame * chunk * sizeof(float)));
+            ctx->mx_terms_bytes = terms_per_frame * chunk * sizeof(float);
+        }
+    }
+    for (int f = 0; f < nframes; f += chunk) {
+        const int nf = nframes - f < chunk ? nframes - f : chunk;
+        const uint8_t* s = d_src + static_cast<size_t>(f) * px * 3;
+        uint8_t* d = d_dst + static_cast<size_t>(f) * px * 3;
+        g.nframes = nf;
+        g.aligned = ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(s) & 3) == 0) ? 1 : 0;
+        const float *qrow = nullptr, *qcol = nullptr;
+        if (p.mx_quirk) {
+            int* srow = ctx->mx_sums;
+            int* asum = ctx->mx_sums + static_cast<size_t>(nf) * rows * 3;
+            float* tr = ctx->mx_terms;
+            float* tc = ctx->mx_terms + static_cast<size_t>(nf) * qpitch * 3;
+            HIP_TRY(ctx, hipMemsetAsync(ctx->mx_sums, 0, sums_per_frame * nf * sizeof(int), ctx->stream));
+            hipLaunchKernelGGL(mx_altsums, dim3((cols + kMxAltCols - 1) / kMxAltCols, (rows + kMxAltRows - 1) / kMxAltRows, nf), dim3(256), 0, ctx->stream, s, srow, asum, g);
+            HIP_TRY(ctx, hipGetLastError());
+            const int most = std::max(rows, 3 * cols);
+            hipLaunchKernelGGL(mx_quirk_terms, dim3((most + 255) / 256, nf), dim3(256), 0, ctx->stream, srow, asum, p.mxt->taps_row, p.mxt->taps_col,
+                               p.mxt->dr, p.mxt->dc, tr, tc, g, qpitch);
+            HIP_TRY(ctx, hipGetLastError());
+            qrow = tr;
+            qcol = tc;
+        }
+        { TimedLaunch t(ctx, 0, nf);
+          HIP_TRY(ctx, p.mx->row_u8(ctx->stream, s, ctx->work, p.mxt->frags_row, g, ctx->num_cus)); }
+        { TimedLaunch t(ctx, 1, nf);
+          HIP_TRY(ctx, p.mx->col_u8(ctx->stream, ctx->work, d, p.mxt->frags_col, g, qrow, qcol, qpitch)); }
+    }
+    return BLUR_OK;
+}
+
 static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes,
                                 int rows, int cols, double sigma, const blur_opts* opts, const CustomKernel* ck)
 {
@@ -1292,7 +1441,8 @@ static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_
     if (chunk > nframes) chunk = nframes;
     if (nframes == 0) return BLUR_OK;
     if (int rc = ensure_work(ctx, p.frame_elems * sizeof(float) * chunk)) return rc;
-    ctx->last_family = p.wr_col ? 2 : ((p.row->fast && p.col->fast) ? 1 : 0);
+    ctx->last_family = p.mx ? 4 : p.wr_col ? 2 : ((p.row->fast && p.col->fast) ? 1 : 0);
+    if (p.mx) return run_mx_u8c3(ctx, d_src, d_dst, nframes, rows, cols, chunk, p);
     for (int f = 0; f < nframes; f += chunk) {
         const int nf = nframes - f < chunk ? nframes - f : chunk;
         const uint8_t* s = d_src + static_cast<size_t>(f) * px * 3;
@@ -1873,6 +2023,19 @@ int blur_convolve_lines_c32_dev(blur_ctx* ctx, const float* d_in, float* d_out, 
     }
     HIP_TRY(ctx, e->lines(ctx->stream, reinterpret_cast<const float2*>(d_in), reinterpret_cast<float2*>(d_out), nlines, ctx->num_cus, ctx->d_w256, tw0, d_m));
     return BLUR_OK;
+}
+
+int blur_mx_fragments(const float* taps, int pad, int nkb, uint16_t* out)
+{
+    if (!taps || !out || pad < 0 || nkb < mx_nkb(pad)) return BLUR_ERR_INVALID;
+    mx_fragments(taps, pad, nkb, out);
+    return BLUR_OK;
+}
+
+int blur_mx_window_blocks(int pad)
+{
+    const MxEntry* e = pad >= 0 ? find_mx_entry(pad) : nullptr;
+    return e ? e->nkb : 0;
 }
 
 int blur_wr_length(int need, int column_role)

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 
 namespace blur_amd {
@@ -305,6 +306,66 @@ void wr_multipliers(const float* karr, int n, int n_ref, bool quirk, float* mult
         mult[f] = static_cast<float>(acc / n);
         if (f > 0 && f < n / 2) mult[n - f] = mult[f];
     }
+}
+
+uint16_t f32_to_f16(float f)
+{
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return static_cast<uint16_t>(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));   // inf / nan
+    if (x >= 0x477ff000u) return static_cast<uint16_t>(sign | 0x7c00u);                                     // rounds to >= 65520: inf
+    if (x < 0x33000001u) return static_cast<uint16_t>(sign);                                                // < 2^-25 (or exactly): zero
+    const int e = static_cast<int>(x >> 23) - 127;
+    uint32_t mant = (x & 0x7fffffu) | 0x800000u;       // 24 bits
+    int shift;                                        // bits to drop from the 24-bit significand
+    uint32_t base;
+    if (e >= -14) { shift = 13; base = static_cast<uint32_t>(e + 15) << 10; mant &= 0x7fffffu; }          // normal
+    else { shift = 13 + (-14 - e); base = 0; }                                                             // subnormal
+    const uint32_t kept = mant >> shift, rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+    uint32_t h = base + kept;
+    if (rem > half || (rem == half && (kept & 1u))) ++h;   // carries propagate into the exponent correctly
+    return static_cast<uint16_t>(sign | h);
+}
+
+float f16_to_f32(uint16_t h)
+{
+    const uint32_t sign = static_cast<uint32_t>(h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) x = sign;
+        else {
+            const float v = std::ldexp(static_cast<float>(m), -24);
+            std::memcpy(&x, &v, 4);
+            x |= sign;
+        }
+    } else if (e == 31) x = sign | 0x7f800000u | (m << 13);
+    else x = sign | ((e + 112) << 23) | (m << 13);
+    float f;
+    std::memcpy(&f, &x, 4);
+    return f;
+}
+
+void mx_fragments(const float* taps, int pad, int nkb, uint16_t* out)
+{
+    const int pada = 8 * (nkb - 2);
+    const float scale = std::ldexp(1.f, kMxScaleLog2);
+    for (int kb = 0; kb < nkb; ++kb)
+        for (int l = 0; l < 64; ++l)
+            for (int j = 0; j < 8; ++j) {
+                const int w = 16 * kb + 8 * (l >> 5) + j, o = l & 31, t = w - o - pada;
+                uint16_t hi = 0, lo = 0;
+                if (t >= -pad && t <= pad) {
+                    const float v = taps[t + pad] * scale;          // exact: power of two
+                    hi = f32_to_f16(v);
+                    lo = f32_to_f16(v - f16_to_f32(hi));            // exact difference (Sterbenz / 11-bit remainder)
+                }
+                const size_t e = (static_cast<size_t>(kb) * 64 + l) * 8 + j;
+                out[e] = hi;
+                out[static_cast<size_t>(nkb) * 512 + e] = lo;
+            }
 }
 
 }  // namespace blur_amd

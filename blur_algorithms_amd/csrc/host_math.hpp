@@ -83,4 +83,21 @@ void wr_tw0(int r0, float* tw0);
 // added to bin n/2 (the alternating sum of the taps does not depend on the even length they are wrapped to).
 void wr_multipliers(const float* karr, int n, int n_ref, bool quirk, float* mult);
 
+// ---- matrix-core engine (mx_kernels.hpp): the convolution as a banded Toeplitz product on f16 MFMA ----------------
+// IEEE binary16 <-> binary32 on the host (round to nearest even; no _Float16 needed from the host compiler)
+uint16_t f32_to_f16(float f);
+float f16_to_f32(uint16_t h);
+constexpr int kMxScaleLog2 = 14;      // taps are scaled by 2^14 before they are split into two halves
+// padding of a 32-output tile's window to whole 8-element operand fragments: PADA = pad rounded up to 8,
+// window = 32 + 2 PADA = 16 * nkb elements
+inline int mx_pada(int pad) { return (pad + 7) & ~7; }
+inline int mx_nkb(int pad) { return 2 + mx_pada(pad) / 8; }
+// Operand fragments of the Toeplitz matrix Tz[w][o] = taps[w - o - PADA + pad] (zero outside the taps), PADA = 8 (nkb - 2)
+// for the kernel's nkb >= mx_nkb(pad), w = 0..16 nkb - 1
+// the window position, o = 0..31 the output: lane l of a wave holds, for block kb, the eight values
+// Tz[16 kb + 8 (l >> 5) + j][l & 31], j = 0..7 -- the B operand of v_mfma_f32_32x32x16_f16 when the data is A (row pass)
+// and equally the A operand when the data is B (column pass).  out: [2][nkb][64][8] binary16; part 0 = hi
+// = f16(tap * 2^14), part 1 = lo = f16(tap * 2^14 - hi).  taps: 2 pad + 1 floats, centre at index pad.
+void mx_fragments(const float* taps, int pad, int nkb, uint16_t* out);
+
 }  // namespace blur_amd

@@ -1,0 +1,514 @@
+// mx_kernels.hpp -- the separable blur as two banded Toeplitz products on the f16 matrix cores (gfx950).
+//
+// Why this exists beside the FFT kernels: both FFT families are bound by vector-ALU issue, not by HBM (DESIGN.md §8:
+// 90 % / 68 % VALU busy at 0.26 of the HBM roofline, and the butterfly arithmetic alone is above the 70 % budget).  For
+// the kernel widths the reference is used with (sigma 20: 131 taps) the same linear map
+//
+//     out[line][o] = sum_t taps[t] * in[line][o + t]                 (inside the crop, Source.cpp:536,558: the circular
+//                                                                     FFT product never wraps into a kept pixel)
+//
+// costs 2 x 176 multiply-adds per output as a dense 32 x 176 Toeplitz tile -- 3 % of the chip's f16 MFMA rate -- so the
+// path becomes what SURVEY 8(d) assumed it was: a stream over HBM.  Precision: the u8 image is exact in binary16; the
+// taps are split into hi + lo halves (22 significant bits); the f32 intermediate is split into hi + lo halves when the
+// column pass loads it; products are exact in the f32 accumulators of v_mfma_f32_32x32x16_f16.  The Nyquist-slot quirk
+// of pffft_() (Source.cpp:420-425) is a rank-one term per line and is added from the exact integer alternating sums of
+// the image (mx_altsums / mx_quirk_terms below).
+//
+//   mx_rowpass_u8   u8 BGR image -> V[row][3 x + c] f32 (row pitch = a multiple of 32 floats)
+//       unit = 32 rows x 128 pixels: reflect-101 + deinterleave + u8 -> f16 into LDS, A = data (32 rows x 16 window
+//       positions), B = Toeplitz fragment (registers), D = 32 rows x 32 outputs; re-interleaved through LDS, float4 stores
+//   mx_colpass_u8   V -> u8 BGR image
+//       a wave owns 32 adjacent floats of V's rows (one 128-byte line per row) and walks down the image: each 16-row
+//       block is loaded ONCE (coalesced, straight into the B operand: lane = column, 8 consecutive rows), split into
+//       hi + lo halves, and multiplied into the (NKB + 1) / 2 output tiles whose windows contain it (A = Toeplitz
+//       fragment of the block's offset in that tile's window).  No LDS, no barrier; channels never need separating
+//       because the convolution runs along rows of V and every interleaved column is independent.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace blur_amd {
+
+typedef _Float16 mx_half8 __attribute__((ext_vector_type(8)));
+typedef float mx_float16 __attribute__((ext_vector_type(16)));
+typedef __fp16 mx_fp16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kMxRowChunk = 128;        // pixels per row-pass unit
+constexpr int kMxStagePitch = 392;      // floats per staged row (384 + 8: the two half-waves land in disjoint banks)
+constexpr float kMxUnscale = 1.f / 16384.f;   // 2^-kMxScaleLog2 (host_math.hpp)
+
+struct MxGeom {
+    int rows, cols, pad;
+    int vpitch;       // floats per row of V: 3 cols rounded up to 32
+    int nframes;
+    int aligned;      // 1: 12-byte pixel groups of the source can be read as three aligned dwords
+    int vrows;        // rows of V per frame: the image rows with their reflect-101 border ABOVE AND BELOW already in place
+                      // (row re of V = image row refl(re - PADA)), so the column pass never reflects: 32 ntiles + 2 PADA
+};
+__host__ __device__ constexpr int mx_vrows(int rows, int nkb) { return 32 * ((rows + 31) / 32) + 32 * ((16 * (nkb - 2) + 31) / 32); }
+
+// LDS pitch (halfs) of one row of the row-pass window: the dword pitch is 4 mod 8, so 16 lanes reading 16 bytes from 16
+// consecutive rows touch 64 distinct banks
+__host__ __device__ constexpr int mx_row_pitch(int nkb)
+{
+    int dw = (kMxRowChunk + 16 * (nkb - 2)) / 2;
+    while ((dw & 7) != 4) ++dw;
+    return 2 * dw;
+}
+__host__ __device__ constexpr size_t mx_row_lds(int nkb)
+{
+    const size_t in = static_cast<size_t>(3) * 32 * mx_row_pitch(nkb) * 2, stage = static_cast<size_t>(32) * kMxStagePitch * 4;
+    return in > stage ? in : stage;
+}
+
+__device__ __forceinline__ int mx_refl(int i, int n)
+{
+    i = i < 0 ? -i : i;
+    i = i >= n ? 2 * (n - 1) - i : i;
+    return min(max(i, 0), n - 1);      // beyond one reflection only zero taps read it: any valid address will do
+}
+
+__device__ __forceinline__ uint32_t mx_pk(float a, float b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(a, b));   // exact: integers 0..255
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// raw pixels of one row-pass unit.  Thread t owns row t >> 3 of the unit's 32 rows and the groups of 4 pixels
+// (t & 7) + 8 k of that row's window, k = 0..PER-1: every address is one per-thread base plus a constant, in global
+// memory (12 bytes per group) and in LDS (8 bytes per group and channel)
+template <int NKB> struct MxRowRaw {
+    static constexpr int PADA = 8 * (NKB - 2), WIN = kMxRowChunk + 2 * PADA, GPR = WIN / 4, PER = (GPR + 7) / 8;
+    uint32_t d[PER][3];
+};
+
+template <int NKB>
+__device__ __forceinline__ void mx_row_issue(MxRowRaw<NKB>& raw, const uint8_t* __restrict__ src, const MxGeom& g, int u, int chunks, int rblocks, int tid)
+{
+    using R = MxRowRaw<NKB>;
+    const int xc = u % chunks, rb = (u / chunks) % rblocks, f = u / (chunks * rblocks);
+    const int x0 = xc * kMxRowChunk, r0 = rb * 32 - R::PADA;          // first image row of the unit's 32 rows of V (mirrored outside)
+    const uint8_t* img = src + static_cast<size_t>(f) * g.rows * g.cols * 3;
+    const int row = tid >> 3, g0 = tid & 7;
+    const int r = mx_refl(r0 + row, g.rows);
+    // interior unit (uniform): every group is whole, inside the image and dword aligned -> branch-free loads the compiler
+    // can issue back to back; otherwise per-pixel reflect-101 (the two edge chunks of a row, odd widths)
+    const bool interior = g.aligned && x0 - R::PADA >= 0 && x0 + kMxRowChunk + R::PADA <= g.cols;
+    if (interior) {
+        // uniform base + 32-bit lane offset (a frame is < 4 GiB)
+        const uint32_t off = (static_cast<uint32_t>(r) * g.cols + static_cast<uint32_t>(x0 - R::PADA + 4 * g0)) * 3u;
+        const uint8_t* p = img + off;
+#pragma unroll
+        for (int k = 0; k < R::PER; ++k) {
+            typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+            const bool in = (R::GPR % 8 == 0) || k < R::PER - 1 || g0 < R::GPR % 8;
+            const u3 t = *reinterpret_cast<const u3*>(in ? p + 96 * k : p);
+            raw.d[k][0] = t[0]; raw.d[k][1] = t[1]; raw.d[k][2] = t[2];
+        }
+    } else {
+        const uint8_t* line = img + static_cast<size_t>(r) * g.cols * 3;
+#pragma unroll                                                        // (a run-time k would put raw.d[] into scratch memory)
+        for (int k = 0; k < R::PER; ++k) {
+            const int xg = x0 - R::PADA + 4 * (g0 + 8 * k);
+            uint32_t b[12];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint8_t* px = line + 3 * mx_refl(xg + q, g.cols);
+                b[3 * q] = px[0]; b[3 * q + 1] = px[1]; b[3 * q + 2] = px[2];
+            }
+            raw.d[k][0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+            raw.d[k][1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+            raw.d[k][2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+        }
+    }
+}
+
+// deinterleave + u8 -> binary16 + write to the LDS window [c][row][PW]
+template <int NKB> __device__ __forceinline__ void mx_row_commit(const MxRowRaw<NKB>& raw, _Float16* in, int tid)
+{
+    using R = MxRowRaw<NKB>;
+    constexpr int PW = mx_row_pitch(NKB);
+    const int row = tid >> 3, g0 = tid & 7;
+    _Float16* base = in + row * PW + 4 * g0;
+#pragma unroll
+    for (int k = 0; k < R::PER; ++k) {
+        if ((R::GPR % 8 == 0) || k < R::PER - 1 || g0 < R::GPR % 8) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int byte = 3 * q + c;
+                    v[q] = static_cast<float>((raw.d[k][byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+                }
+                uint2 w;
+                w.x = mx_pk(v[0], v[1]);
+                w.y = mx_pk(v[2], v[3]);
+                *reinterpret_cast<uint2*>(base + c * 32 * PW + 32 * k) = w;
+            }
+        }
+    }
+}
+
+template <int NKB>
+__global__ __launch_bounds__(256, 2) void mx_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ V, const mx_half8* __restrict__ frags, MxGeom g,
+                                                        int chunks, int rblocks, int nunits)
+{
+    constexpr int PW = mx_row_pitch(NKB);
+    extern __shared__ __attribute__((aligned(16))) unsigned char mx_lds[];
+    _Float16* in = reinterpret_cast<_Float16*>(mx_lds);      // [3][32][PW]
+    float* stage = reinterpret_cast<float*>(mx_lds);         // [32][kMxStagePitch], after the MFMAs have read `in`
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
+
+    mx_half8 th[NKB], tl[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        th[kb] = frags[kb * 64 + lane];
+        tl[kb] = frags[(NKB + kb) * 64 + lane];
+    }
+    MxRowRaw<NKB> raw;
+    int u = blockIdx.x;
+    if (u < nunits) mx_row_issue<NKB>(raw, src, g, u, chunks, rblocks, tid);
+    for (; u < nunits; u += gridDim.x) {
+        const int xc = u % chunks, rb = (u / chunks) % rblocks, f = u / (chunks * rblocks);
+        const int x0 = xc * kMxRowChunk, r0 = rb * 32;                 // r0: row of V
+        mx_row_commit<NKB>(raw, in, tid);
+        __syncthreads();
+        // the next unit's pixels travel while this one is in the matrix cores
+        if (u + static_cast<int>(gridDim.x) < nunits) mx_row_issue<NKB>(raw, src, g, u + gridDim.x, chunks, rblocks, tid);
+        // ---- 4 tiles of 32 outputs x 3 channels = 12 products, 3 per wave
+        mx_float16 acc[3];
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            const int t = wave + 4 * tt, c = t % 3, tile = t / 3;
+            const _Float16* base = in + (c * 32 + m) * PW + tile * 32 + 8 * h;
+            mx_float16 a = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb) {
+                const mx_half8 x = *reinterpret_cast<const mx_half8*>(base + 16 * kb);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, th[kb], a, 0, 0, 0);
+                a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, tl[kb], a, 0, 0, 0);
+            }
+            acc[tt] = a;
+        }
+        __syncthreads();
+        // ---- re-interleave through LDS: D[row][o], row = (reg & 3) + 8 (reg >> 2) + 4 h, o = lane & 31
+#pragma unroll
+        for (int tt = 0; tt < 3; ++tt) {
+            const int t = wave + 4 * tt, c = t % 3, tile = t / 3;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+                stage[row * kMxStagePitch + (tile * 32 + m) * 3 + c] = acc[tt][reg] * kMxUnscale;
+            }
+        }
+        __syncthreads();
+        {   // thread t stores row t >> 3: twelve float4, 128 bytes apart
+            const int row = tid >> 3, q0 = tid & 7;
+            float* vrow = V + (static_cast<size_t>(f) * g.vrows + r0 + row) * g.vpitch + 3 * x0 + 4 * q0;
+            const float* srow = stage + row * kMxStagePitch + 4 * q0;
+            const int room = g.vpitch - 3 * x0 - 4 * q0;               // floats left in the row of V
+#pragma unroll
+            for (int j = 0; j < 12; ++j)
+                if (32 * j < room) *reinterpret_cast<float4*>(vrow + 32 * j) = *reinterpret_cast<const float4*>(srow + 32 * j);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// QUIRK: out += qrow[f][c][r] * (-1)^x + qcol[f][e] * (-1)^r  (e = 3 x + c; qrow rows padded to `qpitch`, a multiple of 32)
+template <int NKB, bool QUIRK>
+__global__ __launch_bounds__(256, 1) void mx_colpass_u8(const float* __restrict__ V, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, MxGeom g,
+                                                        int nstrips, const float* __restrict__ qrow, const float* __restrict__ qcol, int qpitch)
+{
+    // one wave per SIMD (512 registers): 2 NKB fragments + NACC accumulator tiles + a queue of PD blocks in flight
+    constexpr int NACC = (NKB + 1) / 2, PD = (2 * NACC) % 6 == 0 ? 6 : ((2 * NACC) % 4 == 0 ? 4 : 2);
+    const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int f = task / nstrips, s = task - f * nstrips;
+    if (f >= g.nframes) return;
+    const int e = 32 * s + n;
+    const bool valid = e < 3 * g.cols;
+    const float* strip = V + static_cast<size_t>(f) * g.vrows * g.vpitch + 32 * s;                // uniform
+    uint8_t* ostrip = dst + static_cast<size_t>(f) * g.rows * g.cols * 3 + 32 * s;                 // uniform
+    const uint32_t lane_in = (static_cast<uint32_t>(n) + static_cast<uint32_t>(8 * h) * g.vpitch) * 4u;   // byte offset inside a block
+    const uint32_t lane_out = static_cast<uint32_t>(n) + static_cast<uint32_t>(4 * h) * 3u * g.cols;
+    const int rowbytes = 3 * g.cols;
+
+    mx_half8 th[NKB], tl[NKB];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb) {
+        th[kb] = frags[kb * 64 + lane];
+        tl[kb] = frags[(NKB + kb) * 64 + lane];
+    }
+    float sgn_x = 0.f, cpos = 0.5f, cneg = 0.5f;
+    const float* qr = nullptr;
+    if (QUIRK) {
+        sgn_x = ((e / 3) & 1) ? -1.f : 1.f;
+        const float qc = valid ? qcol[static_cast<size_t>(f) * g.vpitch + e] : 0.f;
+        cpos = 0.5f + qc;
+        cneg = 0.5f - qc;
+        qr = qrow + (static_cast<size_t>(f) * 3 + e % 3) * qpitch + 4 * h;
+    }
+
+    const int nblocks = g.vrows / 16;
+    auto load_block = [&](int jb, float (&v)[8]) {
+        // blocks past the end are never part of an emitted tile: read the last one again instead
+        // uniform row pointer + the lane's constant 32-bit byte offset: no vector arithmetic per load
+        const char* base = reinterpret_cast<const char*>(strip + static_cast<size_t>(16 * min(jb, nblocks - 1)) * g.vpitch);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float*>(base + static_cast<size_t>(q) * g.vpitch * 4 + lane_in);
+    };
+
+    float queue[PD][8];
+#pragma unroll
+    for (int k = 0; k < PD; ++k) load_block(k, queue[k]);
+
+    mx_float16 acc[NACC];
+    const mx_float16 zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = zero;
+    const int ntiles = (g.rows + 31) / 32;
+    const int nperiods = ntiles + (NKB - 1) / 2;
+
+    for (int mp = 0; mp < nperiods; mp += NACC) {
+#pragma unroll
+        for (int q = 0; q < NACC; ++q) {
+            const int p = mp + q;
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int slotq = (2 * q + b) % PD;
+                // split the block into hi + lo halves (round to nearest even both times: the remainders have zero mean)
+                mx_half8 v1, v2;
+#pragma unroll
+                for (int k = 0; k < 8; k += 2) {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                    const f2 v = { queue[slotq][k], queue[slotq][k + 1] };
+                    const h2 hi = __builtin_convertvector(v, h2);
+                    const f2 rem = { __builtin_fmaf(static_cast<float>(hi[0]), -1.f, v[0]), __builtin_fmaf(static_cast<float>(hi[1]), -1.f, v[1]) };
+                    const h2 lo = __builtin_convertvector(rem, h2);
+                    v1[k] = hi[0]; v1[k + 1] = hi[1];
+                    v2[k] = lo[0]; v2[k + 1] = lo[1];
+                }
+                load_block(2 * p + b + PD, queue[slotq]);
+#pragma unroll
+                for (int a = 0; 2 * a + b < NKB; ++a) {
+                    const int d = 2 * a + b, slot = (q - a + 2 * NACC) % NACC;
+                    mx_float16 c = d == 0 ? zero : acc[slot];
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[d], v1, c, 0, 0, 0);
+                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v2, c, 0, 0, 0);
+                    acc[slot] = c;
+                }
+                if ((NKB - 1 - b) % 2 == 0) {            // the tile whose last window block this was
+                    const int a = (NKB - 1 - b) / 2, slot = (q - a + 2 * NACC) % NACC, tile = p - a;
+                    if (tile >= 0 && tile < ntiles) {    // uniform
+                        float qv[16];
+                        if (QUIRK) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float4 t4 = *reinterpret_cast<const float4*>(qr + 32 * tile + 8 * k);
+                                qv[4 * k] = t4.x; qv[4 * k + 1] = t4.y; qv[4 * k + 2] = t4.z; qv[4 * k + 3] = t4.w;
+                            }
+                        }
+                        uint8_t* obase = ostrip + static_cast<size_t>(32 * tile) * rowbytes;      // uniform
+                        uint8_t px[16];
+#pragma unroll
+                        for (int reg = 0; reg < 16; ++reg) {
+                            float v = QUIRK ? __builtin_fmaf(qv[reg], sgn_x, (reg & 1) ? cneg : cpos) : 0.5f;
+                            v = __builtin_fmaf(acc[slot][reg], kMxUnscale, v);
+                            px[reg] = static_cast<uint8_t>(static_cast<int>(v));
+                        }
+                        if (32 * tile + 31 < g.rows) {                                              // uniform: a whole tile
+                            if (valid) {
+#pragma unroll
+                                for (int reg = 0; reg < 16; ++reg) (obase + static_cast<size_t>((reg & 3) + 8 * (reg >> 2)) * rowbytes)[lane_out] = px[reg];
+                            }
+                        } else {
+#pragma unroll
+                            for (int reg = 0; reg < 16; ++reg) {
+                                const int rr = (reg & 3) + 8 * (reg >> 2);
+                                if (valid && 32 * tile + rr + 4 * h < g.rows) (obase + static_cast<size_t>(rr) * rowbytes)[lane_out] = px[reg];
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The Nyquist-slot quirk of pffft_() (Source.cpp:420-425) without an FFT.  The reference scales bin N/2 of every padded
+// line with the DC gain; the difference to the true multiplier, delta = m[0] - m[N/2], reaches the output as
+//     delta * (-1)^n * sum_p (-1)^p line[p]            (n, p: positions in the padded line; the zero tail adds nothing)
+// i.e. one alternating sum per line.  With reflect-101 borders that sum is a weighted sum of the image line itself:
+// pixel i sits at p = i + pad and its mirror images (1 <= i <= pad on the left, len-1-pad <= i <= len-2 on the right)
+// all land on positions of the same parity, so weight(i) = (-1)^(i+pad) * (1 + [left mirror] + [right mirror]).
+// Both passes together (row pass R, then column pass on R's output):
+//     out[r][x] = conv2(img)[r][x] + dr (-1)^(x+pad) G(r) + dc (-1)^(r+pad) Scol(x)
+//     G(r)    = sum_t taps[t] Srow(refl(r + t)),            Srow(r) = sum_x wx(x) img[r][x]           (integers)
+//     Scol(x) = sum_t taps[t] A(refl(x + t)) + dr (-1)^(x+pad) Z,   A(x) = sum_r wy(r) img[r][x],  Z = sum_x wx(x) A(x)
+// mx_altsums reads the image once for Srow and A (exact integers: the result does not depend on the order of the
+// additions); mx_quirk_terms turns them into the two float vectors the column kernel adds.
+__device__ __forceinline__ int mx_alt_weight(int i, int len, int pad)
+{
+    const int w = 1 + ((i >= 1 && i <= pad) ? 1 : 0) + ((i >= len - 1 - pad && i <= len - 2) ? 1 : 0);
+    return ((i + pad) & 1) ? -w : w;
+}
+
+constexpr int kMxAltRows = 64;       // image rows per block of mx_altsums
+constexpr int kMxAltCols = 1024;     // pixels per block: one group of 4 pixels (12 bytes) per thread
+#ifdef BLUR_MX_QUIRK_KERNELS   // engine.hip only: plain (non-template) kernels must live in one translation unit
+// grid: (column tiles, row blocks, frames); srow: int [f][rows][3], asum: int [f][3 cols] (zeroed by the caller).
+// A thread keeps the 12 column sums of its group in registers over the block's rows (one atomic each at the end); the row
+// sums are reduced across the wave and added by its first lane.  Integer atomics: the result is exact, whatever the order.
+__global__ __launch_bounds__(256) void mx_altsums(const uint8_t* __restrict__ src, int* __restrict__ srow, int* __restrict__ asum, MxGeom g)
+{
+    const int f = blockIdx.z, r0 = blockIdx.y * kMxAltRows, tid = threadIdx.x;
+    const int xg = blockIdx.x * kMxAltCols + 4 * tid;
+    const uint8_t* img = src + static_cast<size_t>(f) * g.rows * g.cols * 3;
+    int wx[4], a[12];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wx[q] = xg + q < g.cols ? mx_alt_weight(xg + q, g.cols, g.pad) : 0;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) a[k] = 0;
+    const bool fast = g.aligned && xg + 3 < g.cols;
+    const int rend = min(r0 + kMxAltRows, g.rows);
+    auto fetch = [&](int r, uint32_t (&d)[3]) {
+        d[0] = d[1] = d[2] = 0;
+        if (xg >= g.cols) return;
+        const uint8_t* line = img + (static_cast<size_t>(r) * g.cols + xg) * 3;
+        if (fast) {
+            typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+            const u3 t = *reinterpret_cast<const u3*>(line);
+            d[0] = t[0]; d[1] = t[1]; d[2] = t[2];
+        } else {
+            for (int b = 0; b < 12; ++b)
+                if (xg + b / 3 < g.cols) d[b >> 2] |= static_cast<uint32_t>(line[b]) << (8 * (b & 3));
+        }
+    };
+    for (int rr = r0; rr < rend; rr += 4) {
+        uint32_t d[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) fetch(min(rr + k, rend - 1), d[k]);       // four rows in flight
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = rr + k;
+            if (r >= rend) break;                                              // uniform
+            const int wy = mx_alt_weight(r, g.rows, g.pad);
+            int sr[3] = { 0, 0, 0 };
+#pragma unroll
+            for (int b = 0; b < 12; ++b) {
+                const int v = static_cast<int>((d[k][b >> 2] >> (8 * (b & 3))) & 0xffu);
+                a[b] += wy * v;
+                sr[b % 3] += wx[b / 3] * v;
+            }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                int v = sr[c];
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+                if ((tid & 63) == 0 && v != 0) atomicAdd(srow + (static_cast<size_t>(f) * g.rows + r) * 3 + c, v);
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 12; ++b)
+        if (xg + b / 3 < g.cols && a[b] != 0) atomicAdd(asum + static_cast<size_t>(f) * 3 * g.cols + 3 * xg + b, a[b]);
+}
+
+// grid: (blocks over max(rows, 3 cols) / 256, frames); taps: 2 pad + 1 floats (centre at pad)
+// qrow[f][c][r] = dr (-1)^pad G_c(r) (rows padded to qpitch);  qcol[f][e] = dc (-1)^pad Scol(e), e = 3 x + c   (the column
+// kernel multiplies them with (-1)^x and (-1)^r)
+__global__ __launch_bounds__(256) void mx_quirk_terms(const int* __restrict__ srow, const int* __restrict__ asum, const float* __restrict__ taps_row,
+                                                      const float* __restrict__ taps_col, float dr, float dc, float* __restrict__ qrow,
+                                                      float* __restrict__ qcol, MxGeom g, int qpitch)
+{
+    __shared__ double zpart[3][256];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int* sr = srow + static_cast<size_t>(f) * g.rows * 3;
+    const int* as = asum + static_cast<size_t>(f) * 3 * g.cols;
+    // Z_c = sum_x wx(x) A_c(x): every block computes it (a few thousand integer reads from L2)
+    double z[3] = { 0, 0, 0 };
+    for (int x = tid; x < g.cols; x += 256) {
+        const double w = mx_alt_weight(x, g.cols, g.pad);
+        z[0] += w * as[3 * x]; z[1] += w * as[3 * x + 1]; z[2] += w * as[3 * x + 2];
+    }
+    for (int c = 0; c < 3; ++c) zpart[c][tid] = z[c];
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (tid < o) for (int c = 0; c < 3; ++c) zpart[c][tid] += zpart[c][tid + o];
+        __syncthreads();
+    }
+    const double sp = (g.pad & 1) ? -1.0 : 1.0;
+    const int i = blockIdx.x * 256 + tid;
+    if (i < g.rows) {
+        for (int c = 0; c < 3; ++c) {
+            double acc = 0;
+            for (int t = -g.pad; t <= g.pad; ++t) acc += static_cast<double>(taps_col[t + g.pad]) * sr[3 * mx_refl(i + t, g.rows) + c];
+            qrow[(static_cast<size_t>(f) * 3 + c) * qpitch + i] = static_cast<float>(static_cast<double>(dr) * sp * acc);
+        }
+    }
+    if (i < 3 * g.cols) {
+        const int x = i / 3, c = i - 3 * x;
+        double acc = 0;
+        for (int t = -g.pad; t <= g.pad; ++t) acc += static_cast<double>(taps_row[t + g.pad]) * as[3 * mx_refl(x + t, g.cols) + c];
+        acc += static_cast<double>(dr) * (((x + g.pad) & 1) ? -1.0 : 1.0) * zpart[c][0];
+        qcol[static_cast<size_t>(f) * g.vpitch + i] = static_cast<float>(static_cast<double>(dc) * sp * acc);
+    }
+}
+
+#endif  // BLUR_MX_QUIRK_KERNELS
+
+// ---- launchers: one translation unit per NKB (mx_conv_<NKB>.hip) --------------------------------------------------
+struct MxEntry {
+    int nkb;          // window blocks: pad <= 8 (nkb - 2)
+    hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus);
+    hipError_t (*col_u8)(hipStream_t, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qrow, const float* qcol, int qpitch);
+};
+
+template <int NKB> hipError_t mx_launch_row_u8(hipStream_t st, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus)
+{
+    const int chunks = (g.cols + kMxRowChunk - 1) / kMxRowChunk, rblocks = g.vrows / 32;
+    const long long nunits = static_cast<long long>(chunks) * rblocks * g.nframes;
+    if (nunits <= 0) return hipSuccess;
+    const size_t lds = mx_row_lds(NKB);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mx_rowpass_u8<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+    }
+    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int grid = static_cast<int>(nunits < static_cast<long long>(num_cus) * per_cu ? nunits : static_cast<long long>(num_cus) * per_cu);
+    hipLaunchKernelGGL((mx_rowpass_u8<NKB>), dim3(grid), dim3(256), lds, st, src, V, static_cast<const mx_half8*>(frags), g, chunks, rblocks,
+                       static_cast<int>(nunits));
+    return hipGetLastError();
+}
+
+template <int NKB> hipError_t mx_launch_col_u8(hipStream_t st, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qrow, const float* qcol,
+                                               int qpitch)
+{
+    const int nstrips = g.vpitch / 32;
+    const long long tasks = static_cast<long long>(nstrips) * g.nframes;
+    if (tasks <= 0) return hipSuccess;
+    const dim3 grid(static_cast<unsigned>((tasks + 3) / 4));
+    if (qrow)
+        hipLaunchKernelGGL((mx_colpass_u8<NKB, true>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qrow, qcol, qpitch);
+    else
+        hipLaunchKernelGGL((mx_colpass_u8<NKB, false>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qrow, qcol, qpitch);
+    return hipGetLastError();
+}
+
+#define BLUR_MX(NKB_)                                                                                       \
+    namespace blur_amd {                                                                                    \
+    const MxEntry* mx_entry_##NKB_()                                                                        \
+    {                                                                                                       \
+        static const MxEntry e = { NKB_, mx_launch_row_u8<NKB_>, mx_launch_col_u8<NKB_> };                  \
+        return &e;                                                                                          \
+    }                                                                                                       \
+    }
+
+}  // namespace blur_amd

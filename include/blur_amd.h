@@ -233,6 +233,15 @@ int blur_gaussian_u8c3_batch_multi_host(blur_multi* m, const uint8_t* src, uint8
    Two real lines ride in one complex line when the multipliers are even (m[f] = m[n-f]): re and im are then
    convolved independently.  n must be a length the wave-resident kernels support: blur_wr_length(). */
 int blur_convolve_lines_c32_dev(blur_ctx* ctx, const float* d_in, float* d_out, int nlines, int n, const float* multipliers);
+/* ---- matrix-core engine (mx_kernels.hpp): both passes as banded Toeplitz products on v_mfma_f32_32x32x16_f16 ----
+   blur_opts.reserved[3] = 3 selects it for the u8c3 entry points.  Same linear map as the FFT product inside the
+   crop (Source.cpp:536,558), Nyquist-slot quirk (Source.cpp:420-425) included as a rank-one term per line.
+   blur_mx_window_blocks(pad): window blocks (of 16 positions) of the kernel instantiated for this pad, 0 = none.
+   blur_mx_fragments: the Toeplitz operand fragments the kernels load, [2][nkb][64][8] binary16 (hi, lo halves of
+   taps * 2^14); taps: 2 pad + 1 floats, centre at index pad (host only; tests). */
+int blur_mx_window_blocks(int pad);
+int blur_mx_fragments(const float* taps, int pad, int nkb, uint16_t* out);
+
 /* smallest supported transform length >= need for the column (1) or row (0) role; 0 if there is none.
    (The engine's transform length need not be nearestTransformSize(): only the Nyquist-slot term of Source.cpp:420-425
    depends on the reference's length, and the multiplier of bin n/2 reproduces it.) */

@@ -242,3 +242,34 @@ def test_dft_image_restatement_is_self_consistent():
     # displayed columns [0, s1/2) hold negative frequencies, which the reference reads mirrored in the SAME row
     direct = slice(sizes[1] // 2 - border[2], 120)
     assert np.abs(l64[1][:, direct] - want[:, direct])[ok[1][:, direct]].max() < 1e-3
+
+
+def test_mx_fragments_are_the_toeplitz_band_in_two_halves():
+    """blur_mx_fragments (host_math.cpp): binary16 conversion equals numpy's round-to-nearest-even, hi + lo carries the
+    tap to 2^-22, and the fragment layout is Tz[16 kb + 8 (l >> 5) + j][l & 31] = taps[w - o - PADA + pad]"""
+    from blur_algorithms_amd._lib import load
+    lib = load()
+    rng = np.random.default_rng(3)
+    for pad, nkb in ((65, 11), (58, 11), (3, 3), (16, 4), (0, 2)):
+        taps = (rng.random(2 * pad + 1) ** 4).astype(np.float32)
+        taps[0] = 1e-7                                     # a subnormal binary16 after scaling
+        out = np.zeros((2, nkb, 64, 8), np.uint16)
+        assert lib.blur_mx_fragments(taps.ctypes.data, pad, nkb, out.ctypes.data) == 0
+        fr = out.view(np.float16).astype(np.float64)
+        pada = 8 * (nkb - 2)
+        tz = np.zeros((16 * nkb, 32))
+        for w in range(16 * nkb):
+            for o in range(32):
+                t = w - o - pada
+                if -pad <= t <= pad:
+                    tz[w, o] = taps[t + pad]
+        for kb in range(nkb):
+            for l in range(64):
+                want = tz[16 * kb + 8 * (l >> 5):16 * kb + 8 * (l >> 5) + 8, l & 31] * 16384.0
+                hi = want.astype(np.float32).astype(np.float16)
+                assert np.array_equal(out[0, kb, l].view(np.float16), hi)
+                lo = (want.astype(np.float32) - hi.astype(np.float32)).astype(np.float16)
+                assert np.array_equal(out[1, kb, l].view(np.float16), lo)
+                assert np.all(np.abs(fr[0, kb, l] + fr[1, kb, l] - want) <= np.maximum(np.abs(want) * 2.0 ** -21, 2.0 ** -24))
+    assert lib.blur_mx_fragments(taps.ctypes.data, 65, 10, out.ctypes.data) != 0      # window too small for the taps
+    assert lib.blur_mx_window_blocks(65) == 11
