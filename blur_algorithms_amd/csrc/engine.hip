@@ -1032,7 +1032,7 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         const MxEntry* me = find_mx_entry(p.sz.pad);
         const int vpitch = (3 * cols + 31) & ~31;
         if (!me) return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: no kernel instantiated for this pad");
-        if (static_cast<long long>(mx_vrows(rows, me->nkb)) * vpitch >= (1ll << 31) || static_cast<long long>(rows) * cols * 3 >= (1ll << 32))
+        if (static_cast<long long>(mx_vrows(rows, me->nkb)) * vpitch >= (1ll << 30) || static_cast<long long>(rows) * cols * 3 >= (1ll << 32))
             return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: frame too large for 32-bit element offsets");
         if (int rc = mx_get_tables(ctx, me->nkb, sigma, p.sz, ck, &p.mxt)) return rc;
         p.mx = me;
@@ -1379,9 +1379,10 @@ static int run_mx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
 {
     const size_t px = static_cast<size_t>(rows) * cols;
     MxGeom g{ rows, cols, p.sz.pad, p.mx_vpitch, 0, 0, mx_vrows(rows, p.mx->nkb) };
-    const size_t sums_per_frame = (static_cast<size_t>(rows) + cols) * 3;                      // ints: Srow [rows][3], A [3 cols]
-    const int qpitch = 32 * ((rows + 31) / 32);
-    const size_t terms_per_frame = static_cast<size_t>(qpitch) * 3 + p.mx_vpitch;              // floats: qrow [3][qpitch], qcol [vpitch]
+    // ints per frame: Srow [rows][3], A [3 cols], and the partial sums of mx_altsums (nsp per row, nap per column element)
+    const int nsp = 4 * ((cols + kMxAltCols - 1) / kMxAltCols), nap = (rows + kMxAltRows - 1) / kMxAltRows;
+    const size_t sums_per_frame = (static_cast<size_t>(rows) * (1 + nsp) + static_cast<size_t>(cols) * (1 + nap)) * 3;
+    const size_t terms_per_frame = static_cast<size_t>(rows) * 3 + p.mx_vpitch;                // floats: qrow [rows][3], qcol [vpitch]
     if (p.mx_quirk) {
         if (ctx->mx_sums_bytes < sums_per_frame * chunk * sizeof(int)) {
             if (ctx->mx_sums) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->mx_sums)); ctx->mx_sums = nullptr; ctx->mx_sums_bytes = 0; }
@@ -1403,23 +1404,26 @@ static int run_mx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         const float *qrow = nullptr, *qcol = nullptr;
         if (p.mx_quirk) {
             int* srow = ctx->mx_sums;
-            int* asum = ctx->mx_sums + static_cast<size_t>(nf) * rows * 3;
+            int* asum = srow + static_cast<size_t>(nf) * rows * 3;
+            int* spart = asum + static_cast<size_t>(nf) * cols * 3;
+            int* apart = spart + static_cast<size_t>(nf) * nsp * rows * 3;
             float* tr = ctx->mx_terms;
-            float* tc = ctx->mx_terms + static_cast<size_t>(nf) * qpitch * 3;
-            HIP_TRY(ctx, hipMemsetAsync(ctx->mx_sums, 0, sums_per_frame * nf * sizeof(int), ctx->stream));
-            hipLaunchKernelGGL(mx_altsums, dim3((cols + kMxAltCols - 1) / kMxAltCols, (rows + kMxAltRows - 1) / kMxAltRows, nf), dim3(256), 0, ctx->stream, s, srow, asum, g);
+            float* tc = ctx->mx_terms + static_cast<size_t>(nf) * rows * 3;
+            hipLaunchKernelGGL(mx_altsums, dim3(nsp / 4, nap, nf), dim3(256), 0, ctx->stream, s, spart, apart, g);
             HIP_TRY(ctx, hipGetLastError());
-            const int most = std::max(rows, 3 * cols);
-            hipLaunchKernelGGL(mx_quirk_terms, dim3((most + 255) / 256, nf), dim3(256), 0, ctx->stream, srow, asum, p.mxt->taps_row, p.mxt->taps_col,
-                               p.mxt->dr, p.mxt->dc, tr, tc, g, qpitch);
+            hipLaunchKernelGGL(mx_altsums_reduce, dim3((3 * (rows + cols) + 255) / 256, nf), dim3(256), 0, ctx->stream, spart, apart, srow, asum, g, nsp, nap);
+            HIP_TRY(ctx, hipGetLastError());
+            const int rbk = (3 * rows + 255) / 256, cbk = (cols + 255) / 256;
+            hipLaunchKernelGGL(mx_quirk_terms, dim3(rbk + cbk, nf), dim3(256), static_cast<size_t>(256 + 2 * p.sz.pad) * 3 * sizeof(int), ctx->stream, srow, asum,
+                               p.mxt->taps_row, p.mxt->dr, p.mxt->dc, tr, tc, g, rbk);
             HIP_TRY(ctx, hipGetLastError());
             qrow = tr;
             qcol = tc;
         }
         { TimedLaunch t(ctx, 0, nf);
-          HIP_TRY(ctx, p.mx->row_u8(ctx->stream, s, ctx->work, p.mxt->frags_row, g, ctx->num_cus)); }
+          HIP_TRY(ctx, p.mx->row_u8(ctx->stream, s, ctx->work, p.mxt->frags_row, g, ctx->num_cus, qrow)); }
         { TimedLaunch t(ctx, 1, nf);
-          HIP_TRY(ctx, p.mx->col_u8(ctx->stream, ctx->work, d, p.mxt->frags_col, g, qrow, qcol, qpitch)); }
+          HIP_TRY(ctx, p.mx->col_u8(ctx->stream, ctx->work, d, p.mxt->frags_col, g, qcol)); }
     }
     return BLUR_OK;
 }

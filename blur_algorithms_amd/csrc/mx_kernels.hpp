@@ -151,14 +151,16 @@ template <int NKB> __device__ __forceinline__ void mx_row_commit(const MxRowRaw<
     }
 }
 
-template <int NKB>
-__global__ __launch_bounds__(256, 2) void mx_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ V, const mx_half8* __restrict__ frags, MxGeom g,
-                                                        int chunks, int rblocks, int nunits)
+// two workgroups per CU while the fragments (16 NKB registers) leave room for them
+template <int NKB, bool QUIRK>
+__global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ V, const mx_half8* __restrict__ frags, MxGeom g,
+                                                        int chunks, int rblocks, int nunits, const float* __restrict__ qrow)
 {
-    constexpr int PW = mx_row_pitch(NKB);
+    constexpr int PW = mx_row_pitch(NKB), PADA = 8 * (NKB - 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char mx_lds[];
     _Float16* in = reinterpret_cast<_Float16*>(mx_lds);      // [3][32][PW]
     float* stage = reinterpret_cast<float*>(mx_lds);         // [32][kMxStagePitch], after the MFMAs have read `in`
+    float* qs = reinterpret_cast<float*>(mx_lds + mx_row_lds(NKB));   // [3][32]: the quirk's term of the unit's rows (qrow != nullptr)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
 
     mx_half8 th[NKB], tl[NKB];
@@ -174,6 +176,11 @@ __global__ __launch_bounds__(256, 2) void mx_rowpass_u8(const uint8_t* __restric
         const int xc = u % chunks, rb = (u / chunks) % rblocks, f = u / (chunks * rblocks);
         const int x0 = xc * kMxRowChunk, r0 = rb * 32;                 // r0: row of V
         mx_row_commit<NKB>(raw, in, tid);
+        // Nyquist-slot quirk of the row pass (Source.cpp:420-425): V[r][x] += qrow[r][c] * (-1)^x, qrow = dr (-1)^pad Srow
+        if (QUIRK && tid < 96) {
+            const int c = tid >> 5, row = tid & 31;
+            qs[tid] = qrow[(static_cast<size_t>(f) * g.rows + mx_refl(r0 - PADA + row, g.rows)) * 3 + c];
+        }
         __syncthreads();
         // the next unit's pixels travel while this one is in the matrix cores
         if (u + static_cast<int>(gridDim.x) < nunits) mx_row_issue<NKB>(raw, src, g, u + gridDim.x, chunks, rblocks, tid);
@@ -197,10 +204,21 @@ __global__ __launch_bounds__(256, 2) void mx_rowpass_u8(const uint8_t* __restric
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt) {
             const int t = wave + 4 * tt, c = t % 3, tile = t / 3;
+            const float sgn = (m & 1) ? -1.f : 1.f;                      // x = x0 + 32 tile + m: its parity is m's
+            float qv[16];
+            if (QUIRK) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(qs + c * 32 + 8 * k + 4 * h);
+                    qv[4 * k] = t4.x; qv[4 * k + 1] = t4.y; qv[4 * k + 2] = t4.z; qv[4 * k + 3] = t4.w;
+                }
+            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                stage[row * kMxStagePitch + (tile * 32 + m) * 3 + c] = acc[tt][reg] * kMxUnscale;
+                float v = acc[tt][reg] * kMxUnscale;
+                if (QUIRK) v = __builtin_fmaf(qv[reg], sgn, v);
+                stage[row * kMxStagePitch + (tile * 32 + m) * 3 + c] = v;
             }
         }
         __syncthreads();
@@ -218,24 +236,46 @@ __global__ __launch_bounds__(256, 2) void mx_rowpass_u8(const uint8_t* __restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// QUIRK: out += qrow[f][c][r] * (-1)^x + qcol[f][e] * (-1)^r  (e = 3 x + c; qrow rows padded to `qpitch`, a multiple of 32)
+// v - float(hi) for both halves of a packed binary16 pair, one mixed-precision FMA each (hi * -1.0 + v)
+__device__ __forceinline__ void mx_remainder(uint32_t hi2, float v0, float v1, float& r0, float& r1)
+{
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi2), "v"(v0));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi2), "v"(v1));
+}
+
+constexpr uint32_t kMxRsrcWord3 = 0x00020000u;   // raw buffer, 32-bit data format (gfx9 family)
+
+// QUIRK: out += qcol[f][e] * (-1)^r  (e = 3 x + c): the column pass's Nyquist-slot term; the row pass's is already in V
+// All global accesses are buffer instructions: resource = this wave's strip of this frame, vector offset = the lane's
+// constant byte offset, scalar offset = the row -- no vector arithmetic per access, and a store whose offset lies past
+// the image (rows of the last partial tile, columns past 3 cols) is dropped by the bounds check of the resource.
+#ifndef MX_COL_WAVES
+#define MX_COL_WAVES 1
+#endif
 template <int NKB, bool QUIRK>
-__global__ __launch_bounds__(256, 1) void mx_colpass_u8(const float* __restrict__ V, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, MxGeom g,
-                                                        int nstrips, const float* __restrict__ qrow, const float* __restrict__ qcol, int qpitch)
+__global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* __restrict__ V, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, MxGeom g,
+                                                        int nstrips, const float* __restrict__ qcol)
 {
     // one wave per SIMD (512 registers): 2 NKB fragments + NACC accumulator tiles + a queue of PD blocks in flight
-    constexpr int NACC = (NKB + 1) / 2, PD = (2 * NACC) % 6 == 0 ? 6 : ((2 * NACC) % 4 == 0 ? 4 : 2);
+#ifdef MX_COL_PD
+    constexpr int NACC = (NKB + 1) / 2, PD = MX_COL_PD;
+#else
+    // PD blocks of 8 loads + 16 byte stores + 4 term loads stay below the 63 the vmcnt counter can express
+    constexpr int NACC = (NKB + 1) / 2, PD = (2 * NACC) % 4 == 0 ? 4 : ((2 * NACC) % 3 == 0 ? 3 : 2);
+#endif
     const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     const int f = task / nstrips, s = task - f * nstrips;
     if (f >= g.nframes) return;
     const int e = 32 * s + n;
     const bool valid = e < 3 * g.cols;
+    const uint32_t rowbytes = 3u * g.cols, vrowbytes = 4u * g.vpitch;
     const float* strip = V + static_cast<size_t>(f) * g.vrows * g.vpitch + 32 * s;                // uniform
-    uint8_t* ostrip = dst + static_cast<size_t>(f) * g.rows * g.cols * 3 + 32 * s;                 // uniform
-    const uint32_t lane_in = (static_cast<uint32_t>(n) + static_cast<uint32_t>(8 * h) * g.vpitch) * 4u;   // byte offset inside a block
-    const uint32_t lane_out = static_cast<uint32_t>(n) + static_cast<uint32_t>(4 * h) * 3u * g.cols;
-    const int rowbytes = 3 * g.cols;
+    uint8_t* ostrip = dst + static_cast<size_t>(f) * g.rows * rowbytes + 32 * s;                   // uniform
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(strip), 0, g.vrows * vrowbytes - 128u * s, kMxRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(ostrip, 0, g.rows * rowbytes - 32u * s, kMxRsrcWord3);
+    const uint32_t lane_in = 4u * n + 8u * h * vrowbytes;                                          // byte offset inside a block
+    const uint32_t lane_out = valid ? n + 4u * h * rowbytes : 0xfffffff0u;                         // invalid column: out of bounds
 
     mx_half8 th[NKB], tl[NKB];
 #pragma unroll
@@ -243,23 +283,25 @@ __global__ __launch_bounds__(256, 1) void mx_colpass_u8(const float* __restrict_
         th[kb] = frags[kb * 64 + lane];
         tl[kb] = frags[(NKB + kb) * 64 + lane];
     }
-    float sgn_x = 0.f, cpos = 0.5f, cneg = 0.5f;
-    const float* qr = nullptr;
+    float cpos = 0.5f, cneg = 0.5f;                      // + 0.5f of the u8 conversion, +- the column term on even / odd rows
     if (QUIRK) {
-        sgn_x = ((e / 3) & 1) ? -1.f : 1.f;
         const float qc = valid ? qcol[static_cast<size_t>(f) * g.vpitch + e] : 0.f;
         cpos = 0.5f + qc;
         cneg = 0.5f - qc;
-        qr = qrow + (static_cast<size_t>(f) * 3 + e % 3) * qpitch + 4 * h;
     }
 
     const int nblocks = g.vrows / 16;
     auto load_block = [&](int jb, float (&v)[8]) {
         // blocks past the end are never part of an emitted tile: read the last one again instead
-        // uniform row pointer + the lane's constant 32-bit byte offset: no vector arithmetic per load
-        const char* base = reinterpret_cast<const char*>(strip + static_cast<size_t>(16 * min(jb, nblocks - 1)) * g.vpitch);
+        const uint32_t row0 = 16u * min(jb, nblocks - 1) * vrowbytes;                               // uniform
+#ifdef MX_COL_GLOBAL_LOADS
+        const char* base = reinterpret_cast<const char*>(strip) + row0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float*>(base + static_cast<size_t>(q) * g.vpitch * 4 + lane_in);
+        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float*>(base + static_cast<size_t>(q) * vrowbytes + lane_in);
+#else
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, lane_in, row0 + q * vrowbytes, 0));
+#endif
     };
 
     float queue[PD][8];
@@ -281,58 +323,47 @@ __global__ __launch_bounds__(256, 1) void mx_colpass_u8(const float* __restrict_
             for (int b = 0; b < 2; ++b) {
                 const int slotq = (2 * q + b) % PD;
                 // split the block into hi + lo halves (round to nearest even both times: the remainders have zero mean)
-                mx_half8 v1, v2;
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+                u4 w1, w2;
 #pragma unroll
-                for (int k = 0; k < 8; k += 2) {
-                    typedef float f2 __attribute__((ext_vector_type(2)));
-                    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                    const f2 v = { queue[slotq][k], queue[slotq][k + 1] };
-                    const h2 hi = __builtin_convertvector(v, h2);
-                    const f2 rem = { __builtin_fmaf(static_cast<float>(hi[0]), -1.f, v[0]), __builtin_fmaf(static_cast<float>(hi[1]), -1.f, v[1]) };
-                    const h2 lo = __builtin_convertvector(rem, h2);
-                    v1[k] = hi[0]; v1[k + 1] = hi[1];
-                    v2[k] = lo[0]; v2[k + 1] = lo[1];
+                for (int k = 0; k < 4; ++k) {
+                    const f2 v = { queue[slotq][2 * k], queue[slotq][2 * k + 1] };
+                    const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2));
+                    float r0, r1;
+                    mx_remainder(hi, v[0], v[1], r0, r1);
+                    const f2 rem = { r0, r1 };
+                    w1[k] = hi;
+                    w2[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, h2));
                 }
+                const mx_half8 v1 = __builtin_bit_cast(mx_half8, w1), v2 = __builtin_bit_cast(mx_half8, w2);
                 load_block(2 * p + b + PD, queue[slotq]);
 #pragma unroll
                 for (int a = 0; 2 * a + b < NKB; ++a) {
                     const int d = 2 * a + b, slot = (q - a + 2 * NACC) % NACC;
                     mx_float16 c = d == 0 ? zero : acc[slot];
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v1, c, 0, 0, 0);
+#ifndef MX_COL_ONE_MFMA
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[d], v1, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v2, c, 0, 0, 0);
+#endif
                     acc[slot] = c;
                 }
                 if ((NKB - 1 - b) % 2 == 0) {            // the tile whose last window block this was
+                    // (tiles before the first and past the last are stored too: their rows lie outside the resource and the
+                    // bounds check drops them -- no branch, so the whole period stays one scheduling region)
                     const int a = (NKB - 1 - b) / 2, slot = (q - a + 2 * NACC) % NACC, tile = p - a;
-                    if (tile >= 0 && tile < ntiles) {    // uniform
-                        float qv[16];
-                        if (QUIRK) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float4 t4 = *reinterpret_cast<const float4*>(qr + 32 * tile + 8 * k);
-                                qv[4 * k] = t4.x; qv[4 * k + 1] = t4.y; qv[4 * k + 2] = t4.z; qv[4 * k + 3] = t4.w;
-                            }
-                        }
-                        uint8_t* obase = ostrip + static_cast<size_t>(32 * tile) * rowbytes;      // uniform
-                        uint8_t px[16];
+                    {
+                        const uint32_t orow0 = 32u * static_cast<uint32_t>(tile) * rowbytes;        // uniform; tile < 0 wraps far out of bounds
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
-                            float v = QUIRK ? __builtin_fmaf(qv[reg], sgn_x, (reg & 1) ? cneg : cpos) : 0.5f;
-                            v = __builtin_fmaf(acc[slot][reg], kMxUnscale, v);
-                            px[reg] = static_cast<uint8_t>(static_cast<int>(v));
-                        }
-                        if (32 * tile + 31 < g.rows) {                                              // uniform: a whole tile
-                            if (valid) {
-#pragma unroll
-                                for (int reg = 0; reg < 16; ++reg) (obase + static_cast<size_t>((reg & 3) + 8 * (reg >> 2)) * rowbytes)[lane_out] = px[reg];
-                            }
-                        } else {
-#pragma unroll
-                            for (int reg = 0; reg < 16; ++reg) {
-                                const int rr = (reg & 3) + 8 * (reg >> 2);
-                                if (valid && 32 * tile + rr + 4 * h < g.rows) (obase + static_cast<size_t>(rr) * rowbytes)[lane_out] = px[reg];
-                            }
+                            const float v = __builtin_fmaf(acc[slot][reg], kMxUnscale, (reg & 1) ? cneg : cpos);
+#ifdef MX_COL_NO_STORE
+                            if (v == 12345.678f)
+#endif
+                            __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(static_cast<int>(v)), rout, lane_out,
+                                                                 orow0 + static_cast<uint32_t>((reg & 3) + 8 * (reg >> 2)) * rowbytes, 0);
                         }
                     }
                 }
@@ -360,13 +391,14 @@ __device__ __forceinline__ int mx_alt_weight(int i, int len, int pad)
     return ((i + pad) & 1) ? -w : w;
 }
 
-constexpr int kMxAltRows = 64;       // image rows per block of mx_altsums
+constexpr int kMxAltRows = 32;       // image rows per block of mx_altsums
 constexpr int kMxAltCols = 1024;     // pixels per block: one group of 4 pixels (12 bytes) per thread
 #ifdef BLUR_MX_QUIRK_KERNELS   // engine.hip only: plain (non-template) kernels must live in one translation unit
-// grid: (column tiles, row blocks, frames); srow: int [f][rows][3], asum: int [f][3 cols] (zeroed by the caller).
-// A thread keeps the 12 column sums of its group in registers over the block's rows (one atomic each at the end); the row
-// sums are reduced across the wave and added by its first lane.  Integer atomics: the result is exact, whatever the order.
-__global__ __launch_bounds__(256) void mx_altsums(const uint8_t* __restrict__ src, int* __restrict__ srow, int* __restrict__ asum, MxGeom g)
+// grid: (column tiles, row blocks, frames).  No atomics: a block writes its partial sums,
+//   spart[f][ct * 4 + wave][r][3]   the wave's 256 pixels of row r       (ct: column tile, 4 waves each)
+//   apart[f][rb][3 cols]            the block's rows of column element e (rb: row block)
+// and mx_altsums_reduce adds the partials up (integers: exact in any order, and no memset per call).
+__global__ __launch_bounds__(256) void mx_altsums(const uint8_t* __restrict__ src, int* __restrict__ spart, int* __restrict__ apart, MxGeom g)
 {
     const int f = blockIdx.z, r0 = blockIdx.y * kMxAltRows, tid = threadIdx.x;
     const int xg = blockIdx.x * kMxAltCols + 4 * tid;
@@ -378,6 +410,7 @@ __global__ __launch_bounds__(256) void mx_altsums(const uint8_t* __restrict__ sr
     for (int k = 0; k < 12; ++k) a[k] = 0;
     const bool fast = g.aligned && xg + 3 < g.cols;
     const int rend = min(r0 + kMxAltRows, g.rows);
+    int* sp = spart + ((static_cast<size_t>(f) * gridDim.x * 4 + blockIdx.x * 4 + (tid >> 6)) * g.rows) * 3;
     auto fetch = [&](int r, uint32_t (&d)[3]) {
         d[0] = d[1] = d[2] = 0;
         if (xg >= g.cols) return;
@@ -391,12 +424,12 @@ __global__ __launch_bounds__(256) void mx_altsums(const uint8_t* __restrict__ sr
                 if (xg + b / 3 < g.cols) d[b >> 2] |= static_cast<uint32_t>(line[b]) << (8 * (b & 3));
         }
     };
-    for (int rr = r0; rr < rend; rr += 4) {
-        uint32_t d[4][3];
+    for (int rr = r0; rr < rend; rr += 8) {
+        uint32_t d[8][3];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) fetch(min(rr + k, rend - 1), d[k]);       // four rows in flight
+        for (int k = 0; k < 8; ++k) fetch(min(rr + k, rend - 1), d[k]);       // eight rows in flight
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < 8; ++k) {
             const int r = rr + k;
             if (r >= rend) break;                                              // uniform
             const int wy = mx_alt_weight(r, g.rows, g.pad);
@@ -412,53 +445,78 @@ __global__ __launch_bounds__(256) void mx_altsums(const uint8_t* __restrict__ sr
                 int v = sr[c];
 #pragma unroll
                 for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-                if ((tid & 63) == 0 && v != 0) atomicAdd(srow + (static_cast<size_t>(f) * g.rows + r) * 3 + c, v);
+                if ((tid & 63) == 0) sp[3 * r + c] = v;
             }
         }
     }
+    int* ap = apart + (static_cast<size_t>(f) * gridDim.y + blockIdx.y) * 3 * g.cols + 3 * xg;
 #pragma unroll
     for (int b = 0; b < 12; ++b)
-        if (xg + b / 3 < g.cols && a[b] != 0) atomicAdd(asum + static_cast<size_t>(f) * 3 * g.cols + 3 * xg + b, a[b]);
+        if (xg + b / 3 < g.cols) ap[b] = a[b];
 }
 
-// grid: (blocks over max(rows, 3 cols) / 256, frames); taps: 2 pad + 1 floats (centre at pad)
-// qrow[f][c][r] = dr (-1)^pad G_c(r) (rows padded to qpitch);  qcol[f][e] = dc (-1)^pad Scol(e), e = 3 x + c   (the column
-// kernel multiplies them with (-1)^x and (-1)^r)
+// srow[f][r][3] = sum over nsp partials; asum[f][e] = sum over nap partials.  grid: (blocks of 256 over 3 rows + 3 cols, frames)
+__global__ __launch_bounds__(256) void mx_altsums_reduce(const int* __restrict__ spart, const int* __restrict__ apart, int* __restrict__ srow,
+                                                         int* __restrict__ asum, MxGeom g, int nsp, int nap)
+{
+    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x, ns = 3 * g.rows, na = 3 * g.cols;
+    if (i < ns) {
+        int v = 0;
+        for (int k = 0; k < nsp; ++k) v += spart[(static_cast<size_t>(f) * nsp + k) * ns + i];
+        srow[static_cast<size_t>(f) * ns + i] = v;
+    } else if (i - ns < na) {
+        const int e = i - ns;
+        int v = 0;
+        for (int k = 0; k < nap; ++k) v += apart[(static_cast<size_t>(f) * nap + k) * na + e];
+        asum[static_cast<size_t>(f) * na + e] = v;
+    }
+}
+
+// grid: (row blocks + column blocks, frames), 256 outputs per block; taps: 2 pad + 1 floats (centre at pad); dynamic LDS:
+// (256 + 2 pad) * 3 ints.  qrow[f][r][c] = dr (-1)^pad Srow_c(r) (the row kernel multiplies it with (-1)^x and adds it to V);
+// qcol[f][e] = dc (-1)^pad Scol(e), e = 3 x + c (the column kernel multiplies it with (-1)^r)
 __global__ __launch_bounds__(256) void mx_quirk_terms(const int* __restrict__ srow, const int* __restrict__ asum, const float* __restrict__ taps_row,
-                                                      const float* __restrict__ taps_col, float dr, float dc, float* __restrict__ qrow,
-                                                      float* __restrict__ qcol, MxGeom g, int qpitch)
+                                                      float dr, float dc, float* __restrict__ qrow, float* __restrict__ qcol, MxGeom g, int row_blocks)
 {
     __shared__ double zpart[3][256];
+    extern __shared__ int mx_win[];                               // [window][3]
     const int f = blockIdx.y, tid = threadIdx.x;
     const int* sr = srow + static_cast<size_t>(f) * g.rows * 3;
     const int* as = asum + static_cast<size_t>(f) * 3 * g.cols;
-    // Z_c = sum_x wx(x) A_c(x): every block computes it (a few thousand integer reads from L2)
+    const double sp = (g.pad & 1) ? -1.0 : 1.0;
+    if (static_cast<int>(blockIdx.x) < row_blocks) {
+        const int i = blockIdx.x * 256 + tid;
+        if (i < 3 * g.rows) qrow[static_cast<size_t>(f) * g.rows * 3 + i] = static_cast<float>(static_cast<double>(dr) * sp * sr[i]);
+        return;
+    }
+    // Z_c = sum_x wx(x) A_c(x): every column block computes it (a few thousand integer reads from L2)
     double z[3] = { 0, 0, 0 };
     for (int x = tid; x < g.cols; x += 256) {
         const double w = mx_alt_weight(x, g.cols, g.pad);
         z[0] += w * as[3 * x]; z[1] += w * as[3 * x + 1]; z[2] += w * as[3 * x + 2];
     }
     for (int c = 0; c < 3; ++c) zpart[c][tid] = z[c];
+    // Scol for 256 pixels (768 values of e, three per thread): their window of A through LDS
+    const int x0 = (blockIdx.x - row_blocks) * 256, wlen = 256 + 2 * g.pad;
+    for (int k = tid; k < wlen; k += 256) {
+        const int x = mx_refl(x0 - g.pad + k, g.cols);
+        mx_win[3 * k] = as[3 * x]; mx_win[3 * k + 1] = as[3 * x + 1]; mx_win[3 * k + 2] = as[3 * x + 2];
+    }
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
         if (tid < o) for (int c = 0; c < 3; ++c) zpart[c][tid] += zpart[c][tid + o];
         __syncthreads();
     }
-    const double sp = (g.pad & 1) ? -1.0 : 1.0;
-    const int i = blockIdx.x * 256 + tid;
-    if (i < g.rows) {
-        for (int c = 0; c < 3; ++c) {
-            double acc = 0;
-            for (int t = -g.pad; t <= g.pad; ++t) acc += static_cast<double>(taps_col[t + g.pad]) * sr[3 * mx_refl(i + t, g.rows) + c];
-            qrow[(static_cast<size_t>(f) * 3 + c) * qpitch + i] = static_cast<float>(static_cast<double>(dr) * sp * acc);
+    const int x = x0 + tid;
+    if (x < g.cols) {
+        double acc[3] = { 0, 0, 0 };
+        for (int t = 0; t <= 2 * g.pad; ++t) {
+            const double w = taps_row[t];
+            acc[0] += w * mx_win[3 * (tid + t)]; acc[1] += w * mx_win[3 * (tid + t) + 1]; acc[2] += w * mx_win[3 * (tid + t) + 2];
         }
-    }
-    if (i < 3 * g.cols) {
-        const int x = i / 3, c = i - 3 * x;
-        double acc = 0;
-        for (int t = -g.pad; t <= g.pad; ++t) acc += static_cast<double>(taps_row[t + g.pad]) * as[3 * mx_refl(x + t, g.cols) + c];
-        acc += static_cast<double>(dr) * (((x + g.pad) & 1) ? -1.0 : 1.0) * zpart[c][0];
-        qcol[static_cast<size_t>(f) * g.vpitch + i] = static_cast<float>(static_cast<double>(dc) * sp * acc);
+        const double sx = static_cast<double>(dr) * (((x + g.pad) & 1) ? -1.0 : 1.0);
+        for (int c = 0; c < 3; ++c)
+            qcol[static_cast<size_t>(f) * g.vpitch + 3 * x + c] = static_cast<float>(static_cast<double>(dc) * sp * (acc[c] + sx * zpart[c][0]));
     }
 }
 
@@ -467,38 +525,41 @@ __global__ __launch_bounds__(256) void mx_quirk_terms(const int* __restrict__ sr
 // ---- launchers: one translation unit per NKB (mx_conv_<NKB>.hip) --------------------------------------------------
 struct MxEntry {
     int nkb;          // window blocks: pad <= 8 (nkb - 2)
-    hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus);
-    hipError_t (*col_u8)(hipStream_t, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qrow, const float* qcol, int qpitch);
+    hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus, const float* qrow);
+    hipError_t (*col_u8)(hipStream_t, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qcol);
 };
 
-template <int NKB> hipError_t mx_launch_row_u8(hipStream_t st, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus)
+template <int NKB> hipError_t mx_launch_row_u8(hipStream_t st, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus, const float* qrow)
 {
     const int chunks = (g.cols + kMxRowChunk - 1) / kMxRowChunk, rblocks = g.vrows / 32;
     const long long nunits = static_cast<long long>(chunks) * rblocks * g.nframes;
     if (nunits <= 0) return hipSuccess;
-    const size_t lds = mx_row_lds(NKB);
+    const size_t lds = mx_row_lds(NKB) + 96 * sizeof(float);
     if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mx_rowpass_u8<NKB>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mx_rowpass_u8<NKB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(mx_rowpass_u8<NKB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
     }
-    const int per_cu = lds <= 80 * 1024 ? 2 : 1;
+    const int per_cu = (lds <= 80 * 1024 && NKB <= 17) ? 2 : 1;
     const int grid = static_cast<int>(nunits < static_cast<long long>(num_cus) * per_cu ? nunits : static_cast<long long>(num_cus) * per_cu);
-    hipLaunchKernelGGL((mx_rowpass_u8<NKB>), dim3(grid), dim3(256), lds, st, src, V, static_cast<const mx_half8*>(frags), g, chunks, rblocks,
-                       static_cast<int>(nunits));
+    if (qrow)
+        hipLaunchKernelGGL((mx_rowpass_u8<NKB, true>), dim3(grid), dim3(256), lds, st, src, V, static_cast<const mx_half8*>(frags), g, chunks, rblocks,
+                           static_cast<int>(nunits), qrow);
+    else
+        hipLaunchKernelGGL((mx_rowpass_u8<NKB, false>), dim3(grid), dim3(256), lds, st, src, V, static_cast<const mx_half8*>(frags), g, chunks, rblocks,
+                           static_cast<int>(nunits), qrow);
     return hipGetLastError();
 }
 
-template <int NKB> hipError_t mx_launch_col_u8(hipStream_t st, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qrow, const float* qcol,
-                                               int qpitch)
+template <int NKB> hipError_t mx_launch_col_u8(hipStream_t st, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qcol)
 {
     const int nstrips = g.vpitch / 32;
     const long long tasks = static_cast<long long>(nstrips) * g.nframes;
     if (tasks <= 0) return hipSuccess;
     const dim3 grid(static_cast<unsigned>((tasks + 3) / 4));
-    if (qrow)
-        hipLaunchKernelGGL((mx_colpass_u8<NKB, true>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qrow, qcol, qpitch);
-    else
-        hipLaunchKernelGGL((mx_colpass_u8<NKB, false>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qrow, qcol, qpitch);
+    if (qcol) hipLaunchKernelGGL((mx_colpass_u8<NKB, true>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qcol);
+    else hipLaunchKernelGGL((mx_colpass_u8<NKB, false>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qcol);
     return hipGetLastError();
 }
 

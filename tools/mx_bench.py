@@ -1,5 +1,5 @@
 """tools/mx_bench.py -- the matrix-core engine against the FFT engines on the metric's frame (GPU box).
-usage: python tools/mx_bench.py [frames] [rows cols sigma]"""
+usage: python tools/mx_bench.py [-m] [frames] [rows cols sigma]      (-m: the matrix engine only)"""
 import os
 import sys
 import time
@@ -11,13 +11,16 @@ import torch
 
 import blur_algorithms_amd as B
 
+only = "-m" in sys.argv
+if only:
+    sys.argv.remove("-m")
 nf = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 rows, cols, sigma = (int(sys.argv[2]), int(sys.argv[3]), float(sys.argv[4])) if len(sys.argv) > 4 else (2160, 3840, 20.0)
 ctx = B.BlurContext(0)
 g = torch.Generator(device="cuda").manual_seed(1)
 frames = torch.randint(0, 256, (nf, rows, cols, 3), dtype=torch.uint8, device="cuda", generator=g)
 out = torch.empty_like(frames)
-for eng in ("matrix", None):
+for eng in (("matrix",) if only else ("matrix", None)):
     for quirk in (True, False):
         for _ in range(3):
             ctx.pffft_(frames, sigma, out=out, nyquist_quirk=quirk, engine=eng)
@@ -34,6 +37,8 @@ for eng in ("matrix", None):
         ctx.timing_enable(False)
         print("engine %-8s quirk %d: %.3f ms/step  %.1f GP/s   row %.1f us/frame  col %.1f us/frame" % (
             eng, quirk, dt * 1e3, nf * rows * cols / dt / 1e9, t["row_ms"] / max(t["row_frames"], 1) * 1e3, t["col_ms"] / max(t["col_frames"], 1) * 1e3), flush=True)
+if only:
+    sys.exit(0)
 a = ctx.pffft_(frames.clone(), sigma, engine="matrix")
 b = ctx.pffft_(frames.clone(), sigma)
 d = (a.int() - b.int()).abs()
