@@ -96,15 +96,22 @@ def baseline_metric():
         return "megapixels/sec Gaussian blur (\u03c3=20, 4K RGB) at 1/2/4/8 GPUs; % HBM roofline"
 
 
-def pmc_traffic(role, frames_per_launch, wave_resident=True):
+FAMILY_PREFIX = {0: "rowpass_kernel", 1: "fast_", 2: "wr_", 4: "mx_"}
+FAMILY_NAME = {0: "run-time-planned FFT kernels", 1: "specialised rows-first FFT kernels", 2: "wave-resident FFT kernels", 3: "whole-image 2D FFT",
+               4: "matrix-core kernels"}
+
+
+def pmc_traffic(role, frames_per_launch, family=2):
     """(kernel name, HBM bytes per launch) of the row / column kernel from the committed rocprofv3 PMC summary
     (separate FETCH_SIZE / WRITE_SIZE passes of this same command, gfx950 corrections applied there); the
     bytes are None when the summary is missing or was taken with another batching"""
-    default = {True: {"row": "wr_rowpass_u8", "col": "wr_colpass_u8"}, False: {"row": "fast_rowpass3_u8", "col": "fast_colpass_u8"}}[wave_resident][role]
+    prefix = FAMILY_PREFIX.get(family, "?")
+    default = {"mx_": {"row": "mx_rowpass_u8", "col": "mx_colpass_u8"}, "wr_": {"row": "wr_rowpass_u8", "col": "wr_colpass_u8"},
+               }.get(prefix, {"row": "fast_rowpass3_u8", "col": "fast_colpass_u8"})[role]
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         t = json.load(open(path))
-        name = [k for k in t if role + "pass" in k and k.startswith("wr_") == wave_resident][0]
+        name = [k for k in t if role + "pass" in k and k.startswith(prefix)][0]
         e = t[name]
         if abs(e["frames_per_launch"] - frames_per_launch) > 1e-9:
             return name, None
@@ -204,7 +211,7 @@ def reference_sweep(args, torch, B):
             d = (d + 128) % 256 - 128
             rec.update({"ms": round(ms, 4), "megapixels_per_s": round(rows * cols / 1e6 / (ms * 1e-3), 1),
                         "roofline_frac": round(30.0 * rows * cols / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "kernels": {0: "run-time plans", 1: "specialised rows-first", 2: "wave-resident"}.get(fam, "?"),
+                        "kernels": FAMILY_NAME.get(fam, "?"),
                         "max_abs_diff_vs_generic": int(d.abs().max().item()), "frac_diff_vs_generic": round(float((d != 0).float().mean().item()), 6)})
             rec["agrees"] = rec["max_abs_diff_vs_generic"] <= 1 and rec["frac_diff_vs_generic"] < 2e-3
         except B.BlurError as e:
@@ -236,6 +243,8 @@ def main():
                          "reference's test_images tiled to the frame size")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--engine", default="auto", choices=["auto", "matrix", "fft", "wave-resident", "rows-first"],
+                    help="auto: the library's choice (the matrix-core kernels where one exists for the kernel width); the others force a family")
     ap.add_argument("--wave-resident", default="auto", choices=["auto", "on", "off"],
                     help="A/B: the wave-resident kernels (columns first, N = 256 R0) or the rows-first kernels of round 1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -320,6 +329,9 @@ def main():
     out = torch.empty_like(frames)
     ctx = B.BlurContext(local)
     wr = {"auto": None, "on": True, "off": False}[args.wave_resident]
+    eng = None if args.engine == "auto" else args.engine
+    if wr is not None and eng is None:
+        eng = "wave-resident" if wr else "rows-first"          # the round-2 A/B switch still selects an FFT family
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -327,10 +339,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    def timed_run(src, steps, warmup, events):
+    def timed_run(src, steps, warmup, events, engine="default"):
         """W warm-up steps, then exactly `steps` timed steps between two fences; per-step GPU time from events on the launch stream"""
         def step():
-            ctx.pffft_(src, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch, wave_resident=wr)
+            ctx.pffft_(src, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch, wave_resident=wr, engine=(eng if engine == "default" else engine))
         for _ in range(warmup):
             step()
         fence()
@@ -358,18 +370,36 @@ def main():
     if args.data == "synthetic" and not args.no_natural:
         nat_elapsed, _, _ = timed_run(make_frames("natural"), args.steps, 2, False)
         natural = nat_elapsed
+    # the same workload on the FFT kernels (the path north_star describes), a shorter run, for the record
+    fft_value = None
+    if args.engine == "auto" and args.wave_resident == "auto" and not args.no_natural:
+        fsteps = max(3, args.steps // 2)
+        fft_elapsed, _, _ = timed_run(frames, fsteps, 2, False, engine="fft")
+        fft_value = world * fsteps * F * rows * cols / 1e6 / fft_elapsed
+        timed_run(frames, 1, 0, False)                      # leave the context on the default engine (last_family below)
     copy_gbs = None if (args.no_copy or rank != 0) else copy_bandwidth(torch, dev)
 
     if rank == 0:
         px = rows * cols
         mp_total = world * args.steps * F * px / 1e6
         sz = B.pffft_sizing(rows, cols, sigma)
-        lib = B._lib.load() if hasattr(B, "_lib") else None
-        n_row = n_col = None
-        if lib is not None and wr is not False:
+        import ctypes as C
+        lib = B._lib.load()
+        lib.blur_debug_last_family.argtypes = [C.c_void_p]
+        lib.blur_debug_last_family.restype = C.c_int
+        family = lib.blur_debug_last_family(ctx._h)
+        if family == 2:
             n_row, n_col = lib.blur_wr_length(cols + 2 * sz["pad"], 0), lib.blur_wr_length(rows + 2 * sz["pad"], 1)
-        engine = ("wave-resident kernels, columns first, engine FFT lengths %d (rows) / %d (columns)" % (n_row, n_col)) if (n_row and n_col) \
-            else "rows-first kernels at the reference's FFT lengths"
+            engine = "wave-resident FFT kernels, columns first, engine FFT lengths %d (rows) / %d (columns)" % (n_row, n_col)
+        elif family == 4:
+            lib.blur_mx_window_blocks.argtypes = [C.c_int]
+            lib.blur_mx_window_blocks.restype = C.c_int
+            nkb = lib.blur_mx_window_blocks(sz["pad"])
+            engine = ("%s: both passes as banded Toeplitz products on v_mfma_f32_32x32x16_f16 (window %d positions for %d taps, taps and "
+                      "intermediate in hi + lo binary16 halves, f32 accumulation), Nyquist-slot quirk as rank-one terms"
+                      % (FAMILY_NAME[family], 16 * nkb, sz["kSize"]))
+        else:
+            engine = FAMILY_NAME.get(family, "?") + " at the reference's FFT lengths"
         rec = {
             "metric": baseline_metric(),
             "value": round(mp_total / elapsed, 1),
@@ -394,6 +424,8 @@ def main():
         }
         if natural is not None:
             rec["value_natural"] = round(mp_total / natural, 1)      # same workload on natural-image frames (tests/golden crop, tiled)
+        if fft_value is not None:
+            rec["value_fft_kernels"] = round(fft_value, 1)           # same workload, --engine fft (wave-resident FFT kernels)
         frame_bytes = 2 * ALG_BYTES_PER_PX_KERNEL * px
         rec["frame_roofline_frac"] = round((world * args.steps * F * frame_bytes / elapsed / 1e9) / (HBM_PEAK_GBS * world), 4)
         if tm and tm["row_launches"] and tm["col_launches"]:
@@ -401,14 +433,13 @@ def main():
             col_ms = tm["col_ms"] / tm["col_launches"]
             fpl = tm["row_frames"] / tm["row_launches"]            # frames one launch covers
             role, dur = ("col", col_ms) if col_ms >= row_ms else ("row", row_ms)
-            wave_resident = bool(n_row and n_col)
-            name, traffic = pmc_traffic(role, fpl, wave_resident)
+            name, traffic = pmc_traffic(role, fpl, family)
             alg = ALG_BYTES_PER_PX_KERNEL * px * fpl
             achieved = alg / (dur * 1e-3) / 1e9
             rec["roofline"] = {
                 "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_ms": {pmc_traffic("row", fpl, wave_resident)[0]: round(row_ms, 4), pmc_traffic("col", fpl, wave_resident)[0]: round(col_ms, 4)},
+                "avg_launch_ms": {pmc_traffic("row", fpl, family)[0]: round(row_ms, 4), pmc_traffic("col", fpl, family)[0]: round(col_ms, 4)},
                 "frames_per_launch": fpl,
                 "alg_bytes_per_launch": alg,
             }

@@ -132,10 +132,11 @@ class BlurContext:
         # wave-resident kernels (transform length 256 * R0, columns first): None = where they pay (the image fills most
         # of the transform), False = never, True = wherever the image fits one
         o.reserved[3] = 0 if wave_resident is None else (2 if wave_resident else 1)
-        # engine: None = the library's choice; "matrix" = Toeplitz products on the f16 matrix cores (mx_kernels.hpp);
-        # "wave-resident" / "rows-first" = the two FFT kernel families
+        # engine: None = the library's choice (the matrix-core kernels wherever one exists for the kernel width, the FFT
+        # kernels otherwise); "matrix" = Toeplitz products on the f16 matrix cores (mx_kernels.hpp); "fft" = the FFT kernels
+        # with their own measured choice of family; "wave-resident" / "rows-first" = one FFT family
         if engine is not None:
-            o.reserved[3] = {"matrix": 3, "wave-resident": 2, "rows-first": 1}[engine]
+            o.reserved[3] = {"matrix": 3, "wave-resident": 2, "rows-first": 1, "fft": 5}[engine]
         return o
 
     def use_torch_stream(self):

@@ -643,7 +643,7 @@ struct blur_ctx {
     size_t work2_bytes = 0;
     uint8_t* box_tmp = nullptr;
     size_t box_bytes = 0;
-    int last_family = -1;         // kernels the last u8c3 blur used: 0 run-time plans, 1 specialised rows-first, 2 wave-resident, 3 whole-image 2D
+    int last_family = -1;         // kernels the last u8c3 blur used: 0 run-time plans, 1 specialised rows-first, 2 wave-resident, 3 whole-image 2D, 4 matrix-core
     void* host_stage = nullptr;   // device staging of the host-pointer entry points (kept between calls: no allocation per frame)
     size_t host_stage_bytes = 0;
     bool timing = false;
@@ -1027,19 +1027,27 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     const bool quirk = opts ? opts->nyquist_quirk != 0 : true;
     p.col_group = opts ? opts->col_group : 0;
     const bool allow_fast = u8c3 && !(opts && opts->reserved[0] == 1);   // reserved[0] = 1: force the generic kernels (tests)
-    // Matrix-core kernels (mx_kernels.hpp): reserved[3] = 3 asks for them
-    if (allow_fast && opts && opts->reserved[3] == 3) {
+    // Engine choice, blur_opts.reserved[3]:  0 the library's choice -- the matrix-core kernels (mx_kernels.hpp) wherever one is
+    // instantiated for the pad and the frame fits their 32-bit offsets, the FFT kernels otherwise;  3 the matrix-core kernels or
+    // an error;  1 / 2 / 5 the FFT kernels (1 never wave-resident, 2 wave-resident wherever it fits, 5 the measured FFT policy below).
+    const int choice = opts ? opts->reserved[3] : 0;
+    // (allow_wr = false: the caller wants the rows-first float planes themselves, blur_rowpass_u8c3_dev)
+    if (allow_fast && allow_wr && (choice == 0 || choice == 3)) {
         const MxEntry* me = find_mx_entry(p.sz.pad);
         const int vpitch = (3 * cols + 31) & ~31;
-        if (!me) return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: no kernel instantiated for this pad");
-        if (static_cast<long long>(mx_vrows(rows, me->nkb)) * vpitch >= (1ll << 30) || static_cast<long long>(rows) * cols * 3 >= (1ll << 32))
-            return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: frame too large for 32-bit element offsets");
-        if (int rc = mx_get_tables(ctx, me->nkb, sigma, p.sz, ck, &p.mxt)) return rc;
+        const bool fits = me && static_cast<long long>(mx_vrows(rows, me->nkb)) * vpitch < (1ll << 30) && static_cast<long long>(rows) * cols * 3 < (1ll << 32);
+        if (!fits && choice != 0)
+            return fail(ctx, BLUR_ERR_UNSUPPORTED, me ? "matrix-core engine: frame too large for 32-bit element offsets" : "matrix-core engine: no kernel instantiated for this pad");
+        int rc_tables = BLUR_OK;
+        if (fits) rc_tables = mx_get_tables(ctx, me->nkb, sigma, p.sz, ck, &p.mxt);
+        if (fits && rc_tables != BLUR_OK && choice != 0) return rc_tables;
+        if (fits && rc_tables == BLUR_OK) {
         p.mx = me;
         p.mx_vpitch = vpitch;
         p.mx_quirk = quirk;
         p.frame_elems = static_cast<size_t>(mx_vrows(rows, me->nkb)) * vpitch;
         return BLUR_OK;
+        }
     }
     // Wave-resident kernels first (reserved[3] = 1 switches them off): both passes need one, and its LDS must hold the image
     if (allow_fast && allow_wr && !(opts && opts->reserved[3] == 1)) {

@@ -23,12 +23,13 @@ SHAPES = [(270, 480, 20.0), (200, 333, 20.0), (131, 150, 18.0), (540, 960, 21.5)
 
 @pytest.mark.parametrize("rows,cols,sigma", SHAPES)
 @pytest.mark.parametrize("quirk", [False, True])
-def test_matrix_engine_matches_the_oracle(ctx, rows, cols, sigma, quirk):
+@pytest.mark.parametrize("engine", ["matrix", None])
+def test_matrix_engine_matches_the_oracle(ctx, rows, cols, sigma, quirk, engine):
     from oracle import oracle as O
     torch = _torch()
     img = _rand_img(rows, cols, rows + 3 * cols)
     want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=quirk, want_planes=True)
-    got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, nyquist_quirk=quirk, engine="matrix").cpu().numpy()
+    got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, nyquist_quirk=quirk, engine=engine).cpu().numpy()
     assert_u8_parity(got, want, planes)
 
 

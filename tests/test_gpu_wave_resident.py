@@ -121,21 +121,27 @@ def test_batch_equals_single_frames_wave_resident(ctx):
     assert torch.equal(got, again)
 
 
-def test_wave_resident_is_the_default_on_the_metric_frame(ctx):
-    """4K sigma 20 takes the wave-resident kernels by default; switching them off gives the rows-first kernels.  Both
-    obey the parity contract; they differ from each other only at rounding ties."""
+def test_wave_resident_is_the_fft_choice_on_the_metric_frame(ctx):
+    """4K sigma 20: among the FFT kernels (engine="fft") the wave-resident family is chosen; switching it off gives the
+    rows-first kernels.  The library's own default is the matrix-core engine.  All three obey the parity contract; they
+    differ from each other only at rounding ties."""
     torch = _torch()
     from oracle import oracle as O
     img = _rand_img(2160, 3840, 99)
     want, planes = O.pffft_blur_u8c3_f64(img, 20.0, True, want_planes=True)
     t = torch.from_numpy(img).cuda()
-    a = ctx.pffft_(t, 20.0, out=torch.empty_like(t))
+    a = ctx.pffft_(t, 20.0, out=torch.empty_like(t), engine="fft")
     b = ctx.pffft_(t, 20.0, out=torch.empty_like(t), wave_resident=True)
     assert torch.equal(a, b)
     assert_u8_parity(a.cpu().numpy(), want, planes)
     c = ctx.pffft_(t, 20.0, out=torch.empty_like(t), wave_resident=False)
     assert_u8_parity(c.cpu().numpy(), want, planes)
     assert (a != c).float().mean().item() < 1e-4
+    d = ctx.pffft_(t, 20.0, out=torch.empty_like(t))
+    e = ctx.pffft_(t, 20.0, out=torch.empty_like(t), engine="matrix")
+    assert torch.equal(d, e)
+    assert_u8_parity(d.cpu().numpy(), want, planes)
+    assert (a != d).float().mean().item() < 1e-4
 
 
 @pytest.mark.parametrize("role,r0", [("col", r) for r in (3, 4, 5, 6, 8, 9, 10)] + [("row", r) for r in (3, 4, 5, 6, 8, 9, 10, 12, 15, 16)])
