@@ -16,6 +16,7 @@
 // HBM traffic per pixel: 3 B in + 12 B intermediate out, 12 B intermediate in + 3 B out.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -986,6 +987,14 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
         // anything of the kernel array outside +-pad would be lost here: the Toeplitz band is 2 pad + 1 wide
         for (int i = pad + 1; i < n - pad; ++i)
             if (karr[ax][i] != 0.f) return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: kernel wider than 2 pad + 1");
+        // the 24-bit intermediate of the kernels (mx_kernels.hpp) covers [-256, 512): non-negative taps with sum <= 1 keep the
+        // row pass inside 0..255, and a quirk gain m[0] - m[N/2] <= 1/N keeps its term inside +-255
+        {
+            double sum = 0;
+            bool neg = false;
+            for (float t : taps) { sum += t; neg = neg || t < 0.f; }
+            if (neg || sum > 1.0005) return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: taps must be non-negative with sum <= 1");
+        }
         std::vector<uint16_t> fr(static_cast<size_t>(2) * nkb * 512);
         mx_fragments(taps.data(), pad, nkb, fr.data());
         // m[0] and m[n/2] as host_math's kernel_multipliers computes them: float(Re DFT) * (1.f / n)
@@ -1002,6 +1011,7 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
         (ax ? t.frags_col : t.frags_row) = dfr;
         (ax ? t.taps_col : t.taps_row) = dt;
         (ax ? t.dc : t.dr) = m0 - mh;
+        if (std::fabs(static_cast<double>(m0 - mh)) * n > 1.0005) return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: Nyquist gain of the kernel out of range");
     }
     *out = &(ctx->mx_tables[key] = t);
     return BLUR_OK;

@@ -38,6 +38,50 @@ constexpr int kMxRowChunk = 128;        // pixels per row-pass unit
 constexpr int kMxStagePitch = 392;      // floats per staged row (384 + 8: the two half-waves land in disjoint banks)
 constexpr float kMxUnscale = 1.f / 16384.f;   // 2^-kMxScaleLog2 (host_math.hpp)
 
+// The intermediate V between the two kernels is 24-bit fixed point: q = round((v + 256) * 2^14), three bytes per value.
+// Range [-256, 512): the taps are non-negative with sum <= 1 (the engine refuses other kernels), so the row pass gives
+// 0..255, and the row pass's quirk term adds at most +-255 (an image alternating 0 / 255 per column); resolution 6.1e-5 grey
+// levels, i.e. a uniform error of at most 3.1e-5 that the column pass averages over ~70 rows.  A quarter less traffic on
+// the 12 of every 15 B/px that are V.  Layout: [frame][strip of 32 values of a V row][group of 8 rows][lane 0..31][24 bytes]
+// -- the 24 bytes are the lane's 8 consecutive rows, exactly its B-operand fragment of the column pass: two loads per
+// 16-row block instead of eight, 768 contiguous bytes per (strip, row group).
+#ifndef MX_V24
+#define MX_V24 1
+#endif
+constexpr float kMxV24Scale = 16384.f, kMxV24Offset = 256.f;
+struct __attribute__((packed, aligned(8))) MxV24x8 { uint32_t d[6]; };
+
+__device__ __forceinline__ MxV24x8 mx_v24_pack(const float (&v)[8])
+{
+    uint32_t q[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)      // (the clamp only ever acts on columns past the image, whose values are never used)
+        q[k] = static_cast<uint32_t>(__builtin_rintf(fminf(fmaxf(__builtin_fmaf(v[k], kMxV24Scale, kMxV24Offset * kMxV24Scale), 0.f), 16777215.f)));
+    MxV24x8 r;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        r.d[3 * t] = q[4 * t] | (q[4 * t + 1] << 24);
+        r.d[3 * t + 1] = (q[4 * t + 1] >> 8) | (q[4 * t + 2] << 16);
+        r.d[3 * t + 2] = (q[4 * t + 2] >> 16) | (q[4 * t + 3] << 8);
+    }
+    return r;
+}
+
+__device__ __forceinline__ void mx_v24_unpack(const uint32_t (&d)[6], float (&v)[8])
+{
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const uint32_t q0 = d[3 * t] & 0xffffffu;
+        const uint32_t q1 = __builtin_amdgcn_alignbit(d[3 * t + 1], d[3 * t], 24) & 0xffffffu;
+        const uint32_t q2 = __builtin_amdgcn_alignbit(d[3 * t + 2], d[3 * t + 1], 16) & 0xffffffu;
+        const uint32_t q3 = d[3 * t + 2] >> 8;
+        v[4 * t] = __builtin_fmaf(static_cast<float>(q0), 1.f / kMxV24Scale, -kMxV24Offset);
+        v[4 * t + 1] = __builtin_fmaf(static_cast<float>(q1), 1.f / kMxV24Scale, -kMxV24Offset);
+        v[4 * t + 2] = __builtin_fmaf(static_cast<float>(q2), 1.f / kMxV24Scale, -kMxV24Offset);
+        v[4 * t + 3] = __builtin_fmaf(static_cast<float>(q3), 1.f / kMxV24Scale, -kMxV24Offset);
+    }
+}
+
 struct MxGeom {
     int rows, cols, pad;
     int vpitch;       // floats per row of V: 3 cols rounded up to 32
@@ -81,10 +125,12 @@ __device__ __forceinline__ uint32_t mx_pk(float a, float b)
 template <int NKB> struct MxRowRaw {
     static constexpr int PADA = 8 * (NKB - 2), WIN = kMxRowChunk + 2 * PADA, GPR = WIN / 4, PER = (GPR + 7) / 8;
     uint32_t d[PER][3];
+    float q;            // the quirk's term of (row tid & 31, channel tid >> 5) of the unit, threads 0..95 (QUIRK kernels)
 };
 
 template <int NKB>
-__device__ __forceinline__ void mx_row_issue(MxRowRaw<NKB>& raw, const uint8_t* __restrict__ src, const MxGeom& g, int u, int chunks, int rblocks, int tid)
+__device__ __forceinline__ void mx_row_issue(MxRowRaw<NKB>& raw, const uint8_t* __restrict__ src, const MxGeom& g, int u, int chunks, int rblocks, int tid,
+                                             const float* __restrict__ qrow)
 {
     using R = MxRowRaw<NKB>;
     const int xc = u % chunks, rb = (u / chunks) % rblocks, f = u / (chunks * rblocks);
@@ -92,6 +138,7 @@ __device__ __forceinline__ void mx_row_issue(MxRowRaw<NKB>& raw, const uint8_t* 
     const uint8_t* img = src + static_cast<size_t>(f) * g.rows * g.cols * 3;
     const int row = tid >> 3, g0 = tid & 7;
     const int r = mx_refl(r0 + row, g.rows);
+    if (qrow && tid < 96) raw.q = qrow[(static_cast<size_t>(f) * g.rows + mx_refl(r0 + (tid & 31), g.rows)) * 3 + (tid >> 5)];
     // interior unit (uniform): every group is whole, inside the image and dword aligned -> branch-free loads the compiler
     // can issue back to back; otherwise per-pixel reflect-101 (the two edge chunks of a row, odd widths)
     const bool interior = g.aligned && x0 - R::PADA >= 0 && x0 + kMxRowChunk + R::PADA <= g.cols;
@@ -156,7 +203,7 @@ template <int NKB, bool QUIRK>
 __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ V, const mx_half8* __restrict__ frags, MxGeom g,
                                                         int chunks, int rblocks, int nunits, const float* __restrict__ qrow)
 {
-    constexpr int PW = mx_row_pitch(NKB), PADA = 8 * (NKB - 2);
+    constexpr int PW = mx_row_pitch(NKB);
     extern __shared__ __attribute__((aligned(16))) unsigned char mx_lds[];
     _Float16* in = reinterpret_cast<_Float16*>(mx_lds);      // [3][32][PW]
     float* stage = reinterpret_cast<float*>(mx_lds);         // [32][kMxStagePitch], after the MFMAs have read `in`
@@ -171,19 +218,16 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
     }
     MxRowRaw<NKB> raw;
     int u = blockIdx.x;
-    if (u < nunits) mx_row_issue<NKB>(raw, src, g, u, chunks, rblocks, tid);
+    if (u < nunits) mx_row_issue<NKB>(raw, src, g, u, chunks, rblocks, tid, QUIRK ? qrow : nullptr);
     for (; u < nunits; u += gridDim.x) {
         const int xc = u % chunks, rb = (u / chunks) % rblocks, f = u / (chunks * rblocks);
         const int x0 = xc * kMxRowChunk, r0 = rb * 32;                 // r0: row of V
         mx_row_commit<NKB>(raw, in, tid);
         // Nyquist-slot quirk of the row pass (Source.cpp:420-425): V[r][x] += qrow[r][c] * (-1)^x, qrow = dr (-1)^pad Srow
-        if (QUIRK && tid < 96) {
-            const int c = tid >> 5, row = tid & 31;
-            qs[tid] = qrow[(static_cast<size_t>(f) * g.rows + mx_refl(r0 - PADA + row, g.rows)) * 3 + c];
-        }
+        if (QUIRK && tid < 96) qs[tid] = raw.q;
         __syncthreads();
         // the next unit's pixels travel while this one is in the matrix cores
-        if (u + static_cast<int>(gridDim.x) < nunits) mx_row_issue<NKB>(raw, src, g, u + gridDim.x, chunks, rblocks, tid);
+        if (u + static_cast<int>(gridDim.x) < nunits) mx_row_issue<NKB>(raw, src, g, u + gridDim.x, chunks, rblocks, tid, QUIRK ? qrow : nullptr);
         // ---- 4 tiles of 32 outputs x 3 channels = 12 products, 3 per wave
         mx_float16 acc[3];
 #pragma unroll
@@ -222,6 +266,22 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
             }
         }
         __syncthreads();
+#if MX_V24
+        {   // 12 strips x 4 row groups x 32 lanes = 1536 fragments of 24 bytes, six per thread; a wave stores 2 x 768 contiguous bytes
+            unsigned char* vbase = reinterpret_cast<unsigned char*>(V) + static_cast<size_t>(f) * (g.vpitch / 32) * (g.vrows / 8) * 768;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int it = tid + 256 * k, seg = it >> 5, n = it & 31, sidx = seg >> 2, rgi = seg & 3;
+                const int strip = (3 * x0) / 32 + sidx;
+                if (strip < g.vpitch / 32) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = stage[(8 * rgi + j) * kMxStagePitch + 32 * sidx + n];
+                    *reinterpret_cast<MxV24x8*>(vbase + (static_cast<size_t>(strip) * (g.vrows / 8) + (r0 / 8 + rgi)) * 768 + 24 * n) = mx_v24_pack(v);
+                }
+            }
+        }
+#else
         {   // thread t stores row t >> 3: twelve float4, 128 bytes apart
             const int row = tid >> 3, q0 = tid & 7;
             float* vrow = V + (static_cast<size_t>(f) * g.vrows + r0 + row) * g.vpitch + 3 * x0 + 4 * q0;
@@ -231,6 +291,7 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
             for (int j = 0; j < 12; ++j)
                 if (32 * j < room) *reinterpret_cast<float4*>(vrow + 32 * j) = *reinterpret_cast<const float4*>(srow + 32 * j);
         }
+#endif
         __syncthreads();
     }
 }
@@ -269,12 +330,25 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
     if (f >= g.nframes) return;
     const int e = 32 * s + n;
     const bool valid = e < 3 * g.cols;
-    const uint32_t rowbytes = 3u * g.cols, vrowbytes = 4u * g.vpitch;
+    const uint32_t rowbytes = 3u * g.cols;
+#if !MX_V24
+    const uint32_t vrowbytes = 4u * g.vpitch;
+#endif
+#if MX_V24
+    const uint32_t stripbytes = static_cast<uint32_t>(g.vrows / 8) * 768u;
+    const unsigned char* strip = reinterpret_cast<const unsigned char*>(V) + (static_cast<size_t>(f) * nstrips + s) * stripbytes;   // uniform
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(strip), 0, stripbytes, kMxRsrcWord3);
+#else
     const float* strip = V + static_cast<size_t>(f) * g.vrows * g.vpitch + 32 * s;                // uniform
-    uint8_t* ostrip = dst + static_cast<size_t>(f) * g.rows * rowbytes + 32 * s;                   // uniform
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(strip), 0, g.vrows * vrowbytes - 128u * s, kMxRsrcWord3);
+#endif
+    uint8_t* ostrip = dst + static_cast<size_t>(f) * g.rows * rowbytes + 32 * s;                   // uniform
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(ostrip, 0, g.rows * rowbytes - 32u * s, kMxRsrcWord3);
+#if MX_V24
+    const uint32_t lane_in = 24u * n + 768u * h;                                                   // byte offset inside a block (two row groups)
+#else
     const uint32_t lane_in = 4u * n + 8u * h * vrowbytes;                                          // byte offset inside a block
+#endif
     const uint32_t lane_out = valid ? n + 4u * h * rowbytes : 0xfffffff0u;                         // invalid column: out of bounds
 
     mx_half8 th[NKB], tl[NKB];
@@ -291,20 +365,28 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
     }
 
     const int nblocks = g.vrows / 16;
+#if MX_V24
+    constexpr int QW = 6;
+    auto load_block = [&](int jb, uint32_t (&d)[6]) {
+        // blocks past the end are never part of an emitted tile: read the last one again instead
+        const uint32_t off = 1536u * min(jb, nblocks - 1);                                          // uniform
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+        const u4 a = __builtin_amdgcn_raw_buffer_load_b128(rin, lane_in, off, 0);
+        const u2 b = __builtin_amdgcn_raw_buffer_load_b64(rin, lane_in + 16u, off, 0);
+        d[0] = a[0]; d[1] = a[1]; d[2] = a[2]; d[3] = a[3]; d[4] = b[0]; d[5] = b[1];
+    };
+    uint32_t queue[PD][QW];
+#else
+    constexpr int QW = 8;
     auto load_block = [&](int jb, float (&v)[8]) {
         // blocks past the end are never part of an emitted tile: read the last one again instead
         const uint32_t row0 = 16u * min(jb, nblocks - 1) * vrowbytes;                               // uniform
-#ifdef MX_COL_GLOBAL_LOADS
-        const char* base = reinterpret_cast<const char*>(strip) + row0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = *reinterpret_cast<const float*>(base + static_cast<size_t>(q) * vrowbytes + lane_in);
-#else
 #pragma unroll
         for (int q = 0; q < 8; ++q) v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, lane_in, row0 + q * vrowbytes, 0));
-#endif
     };
-
-    float queue[PD][8];
+    float queue[PD][QW];
+#endif
 #pragma unroll
     for (int k = 0; k < PD; ++k) load_block(k, queue[k]);
 
@@ -327,9 +409,16 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
                 typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
                 u4 w1, w2;
+                float vv[8];
+#if MX_V24
+                mx_v24_unpack(queue[slotq], vv);
+#else
+#pragma unroll
+                for (int k = 0; k < 8; ++k) vv[k] = queue[slotq][k];
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const f2 v = { queue[slotq][2 * k], queue[slotq][2 * k + 1] };
+                    const f2 v = { vv[2 * k], vv[2 * k + 1] };
                     const uint32_t hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, h2));
                     float r0, r1;
                     mx_remainder(hi, v[0], v[1], r0, r1);
@@ -391,6 +480,19 @@ __device__ __forceinline__ int mx_alt_weight(int i, int len, int pad)
     return ((i + pad) & 1) ? -w : w;
 }
 
+// sum over the 64 lanes on the vector ALU (DPP row shifts, then the two row broadcasts): the total is in lane 63.
+// (__shfl_xor is ds_bpermute: eighteen of them per image row made the LDS crossbar this kernel's bottleneck.)
+__device__ __forceinline__ int mx_wave_sum_lane63(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8   -> lane 15 of every row of 16: the row's sum
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);    // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);    // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 constexpr int kMxAltRows = 32;       // image rows per block of mx_altsums
 constexpr int kMxAltCols = 1024;     // pixels per block: one group of 4 pixels (12 bytes) per thread
 #ifdef BLUR_MX_QUIRK_KERNELS   // engine.hip only: plain (non-template) kernels must live in one translation unit
@@ -442,10 +544,8 @@ __global__ __launch_bounds__(256) void mx_altsums(const uint8_t* __restrict__ sr
             }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                int v = sr[c];
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-                if ((tid & 63) == 0) sp[3 * r + c] = v;
+                const int v = mx_wave_sum_lane63(sr[c]);
+                if ((tid & 63) == 63) sp[3 * r + c] = v;
             }
         }
     }
