@@ -1011,7 +1011,8 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
         (ax ? t.frags_col : t.frags_row) = dfr;
         (ax ? t.taps_col : t.taps_row) = dt;
         (ax ? t.dc : t.dr) = m0 - mh;
-        if (std::fabs(static_cast<double>(m0 - mh)) * n > 1.0005) return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: Nyquist gain of the kernel out of range");
+        if (std::fabs(static_cast<double>(m0 - mh)) * n > 1.003)   // (a truncated Gaussian reaches 1.0015: its alternating sum is slightly negative)
+            return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: Nyquist gain of the kernel out of range");
     }
     *out = &(ctx->mx_tables[key] = t);
     return BLUR_OK;

@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
         if (QUIRK && tid < 96) qs[tid] = raw.q;
         __syncthreads();
         // the next unit's pixels travel while this one is in the matrix cores
+#ifndef MX_ROW_NOLOAD
         if (u + static_cast<int>(gridDim.x) < nunits) mx_row_issue<NKB>(raw, src, g, u + gridDim.x, chunks, rblocks, tid, QUIRK ? qrow : nullptr);
+#endif
         // ---- 4 tiles of 32 outputs x 3 channels = 12 products, 3 per wave
         mx_float16 acc[3];
 #pragma unroll
@@ -238,6 +240,9 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 const mx_half8 x = *reinterpret_cast<const mx_half8*>(base + 16 * kb);
+#ifdef MX_ROW_NOMFMA
+                if (kb > 0) continue;
+#endif
                 a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, th[kb], a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, tl[kb], a, 0, 0, 0);
             }
@@ -277,6 +282,9 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = stage[(8 * rgi + j) * kMxStagePitch + 32 * sidx + n];
+#ifdef MX_ROW_NOSTORE
+                    if (v[0] == 12345.678f)
+#endif
                     *reinterpret_cast<MxV24x8*>(vbase + (static_cast<size_t>(strip) * (g.vrows / 8) + (r0 / 8 + rgi)) * 768 + 24 * n) = mx_v24_pack(v);
                 }
             }
@@ -560,14 +568,31 @@ __global__ __launch_bounds__(256) void mx_altsums_reduce(const int* __restrict__
                                                          int* __restrict__ asum, MxGeom g, int nsp, int nap)
 {
     const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x, ns = 3 * g.rows, na = 3 * g.cols;
+    // (eight independent loads per trip: a serial chain of nap dependent L2 round trips was most of this kernel's time)
     if (i < ns) {
-        int v = 0;
-        for (int k = 0; k < nsp; ++k) v += spart[(static_cast<size_t>(f) * nsp + k) * ns + i];
+        const int* p = spart + static_cast<size_t>(f) * nsp * ns + i;
+        int v = 0, k = 0;
+        for (; k + 8 <= nsp; k += 8) {
+            int t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = p[static_cast<size_t>(k + j) * ns];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v += t[j];
+        }
+        for (; k < nsp; ++k) v += p[static_cast<size_t>(k) * ns];
         srow[static_cast<size_t>(f) * ns + i] = v;
     } else if (i - ns < na) {
         const int e = i - ns;
-        int v = 0;
-        for (int k = 0; k < nap; ++k) v += apart[(static_cast<size_t>(f) * nap + k) * na + e];
+        const int* p = apart + static_cast<size_t>(f) * nap * na + e;
+        int v = 0, k = 0;
+        for (; k + 8 <= nap; k += 8) {
+            int t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = p[static_cast<size_t>(k + j) * na];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v += t[j];
+        }
+        for (; k < nap; ++k) v += p[static_cast<size_t>(k) * na];
         asum[static_cast<size_t>(f) * na + e] = v;
     }
 }
@@ -610,6 +635,7 @@ __global__ __launch_bounds__(256) void mx_quirk_terms(const int* __restrict__ sr
     const int x = x0 + tid;
     if (x < g.cols) {
         double acc[3] = { 0, 0, 0 };
+#pragma unroll 4
         for (int t = 0; t <= 2 * g.pad; ++t) {
             const double w = taps_row[t];
             acc[0] += w * mx_win[3 * (tid + t)]; acc[1] += w * mx_win[3 * (tid + t) + 1]; acc[2] += w * mx_win[3 * (tid + t) + 2];

@@ -40,3 +40,65 @@ def test_matrix_engine_batch_and_constant(ctx):
     assert torch.equal(ctx.pffft_(frames.clone(), 20.0, engine="matrix"), one)
     const = torch.full((200, 300, 3), 201, dtype=torch.uint8, device="cuda")
     assert int((ctx.pffft_(const.clone(), 20.0, engine="matrix") != 201).sum()) == 0
+
+
+# one sigma per instantiated window size (NKB = 3, 5, ..., 23: pad 0..168), odd image sizes, both quirk settings;
+# rows, cols > pad.  sigma 2.5 -> pad 7 (NKB 3) ... sigma 50 -> pad 166 (NKB 23)
+EVERY_WINDOW = [(2.5, 3), (7.5, 5), (12.5, 7), (17.0, 9), (22.0, 11), (26.5, 13), (31.5, 15), (36.5, 17), (41.0, 19), (46.0, 21), (50.0, 23)]
+
+
+@pytest.mark.parametrize("sigma,nkb", EVERY_WINDOW)
+def test_every_instantiated_window(ctx, sigma, nkb):
+    import blur_algorithms_amd as B
+    from oracle import oracle as O
+    torch = _torch()
+    lib = B._lib.load()
+    rows, cols = 171 + 2 * nkb, 333
+    pad = B.pffft_sizing(rows, cols, sigma)["pad"]
+    assert lib.blur_mx_window_blocks(pad) == nkb
+    img = _rand_img(rows, cols, nkb)
+    for quirk in (True, False):
+        want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=quirk, want_planes=True)
+        got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, nyquist_quirk=quirk, engine="matrix").cpu().numpy()
+        assert_u8_parity(got, want, planes)
+
+
+def test_wider_kernels_and_signed_taps_fall_back_to_the_fft_kernels(ctx):
+    """pad > 168 has no matrix-core kernel; a kernel with negative taps does not fit the 24-bit intermediate: the
+    library's own choice is then the FFT engine, and asking for the matrix engine explicitly is an error"""
+    import ctypes as C
+    import blur_algorithms_amd as B
+    from blur_algorithms_amd.api import BlurError
+    torch = _torch()
+    lib = B._lib.load()
+    lib.blur_debug_last_family.argtypes = [C.c_void_p]
+    lib.blur_debug_last_family.restype = C.c_int
+    img = torch.from_numpy(_rand_img(400, 420, 1)).cuda()
+    ctx.pffft_(img.clone(), 60.0)
+    assert lib.blur_debug_last_family(ctx._h) != 4
+    ctx.pffft_(img.clone(), 20.0)
+    assert lib.blur_debug_last_family(ctx._h) == 4
+    with pytest.raises(BlurError):
+        ctx.pffft_(img.clone(), 60.0, engine="matrix")
+    sharpen = np.array([-0.25, 1.5, -0.25], np.float32)          # symmetric, sum 1, negative side taps
+    ctx.separable(img.clone(), sharpen)
+    assert lib.blur_debug_last_family(ctx._h) != 4
+    smooth = np.array([0.25, 0.5, 0.25], np.float32)
+    ctx.separable(img.clone(), smooth)
+    assert lib.blur_debug_last_family(ctx._h) == 4
+
+
+def test_matrix_engine_extreme_images(ctx):
+    """the images that stretch the 24-bit intermediate: columns alternating 0 / 255 (the row pass's quirk term is
+    +-255 on top of a value of 127.5) and rows alternating (the column term), all 255, all 0"""
+    from oracle import oracle as O
+    torch = _torch()
+    rows, cols, sigma = 150, 262, 20.0
+    x = np.arange(cols)[None, :, None]
+    y = np.arange(rows)[:, None, None]
+    for name, img in (("columns", np.broadcast_to(255 * (x & 1), (rows, cols, 3))), ("rows", np.broadcast_to(255 * (y & 1), (rows, cols, 3))),
+                      ("checker", np.broadcast_to(255 * ((x + y) & 1), (rows, cols, 3))), ("white", np.full((rows, cols, 3), 255)), ("black", np.zeros((rows, cols, 3)))):
+        img = np.ascontiguousarray(img).astype(np.uint8)
+        want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=True, want_planes=True)
+        got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, engine="matrix").cpu().numpy()
+        assert_u8_parity(got, want, planes), name
