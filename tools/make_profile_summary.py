@@ -32,7 +32,7 @@ def mean_counters(sub):
     for f in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            m = re.search(r"((?:fast|wr)_(?:row|col)pass\d*_u8)", k)
+            m = re.search(r"((?:fast|wr|mx)_(?:row|col)pass\d*_u8|mx_altsums_reduce|mx_altsums|mx_quirk_terms)", k)
             name = m.group(1) if m else None
             if name:
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -76,6 +76,8 @@ for k in sorted(summary):
     # on their known input sizes -- FETCH_SIZE reads 99.97 MB for the 199.07 MB of u8 frames and 402.6 MB for the 796-800 MB
     # of float intermediate, i.e. one half in both cases, like the wide reads: f = 2
     f = 1.0 if k == "fast_rowpass_u8" else 2.0
+    if not k.endswith("pass_u8") and not k.endswith("pass3_u8"):
+        continue                                       # the quirk's small kernels: counters kept in *_pmc_counters.json only
     if "FETCH_SIZE" in summary[k] and "WRITE_SIZE" in summary[k]:
         fetch, write = summary[k]["FETCH_SIZE"] * 1024, summary[k]["WRITE_SIZE"] * 1024
         traffic[k] = {
@@ -86,5 +88,12 @@ for k in sorted(summary):
             "l2_hit_rate": round(summary[k]["TCC_HIT_sum"] / (summary[k]["TCC_HIT_sum"] + summary[k]["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in summary[k] else None,
             "source": "%s_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, separate runs of bench.py)" % tag,
         }
+# keep the entries of kernel families this run did not execute (the FFT kernels when the bench ran the matrix-core engine, and back)
+try:
+    merged = json.load(open(os.path.join(out, "pmc_traffic.json")))
+except Exception:
+    merged = {}
+merged.update(traffic)
+traffic = merged
 json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1, sort_keys=True)
 print(json.dumps(traffic, indent=1))
