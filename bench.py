@@ -251,6 +251,9 @@ def main():
     ap.add_argument("--no-events", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-natural", action="store_true", help="skip the second (natural-image) timed run")
     ap.add_argument("--no-copy", action="store_true", help="skip the streaming-copy bandwidth measurement")
+    ap.add_argument("--settle", type=float, default=0.4,
+                    help="seconds of the same workload run BEFORE the W warm-up steps (untimed): first-touch of the workspaces, "
+                         "clock and power state; the first few milliseconds after an idle gap run 5-10 %% slower (DESIGN.md)")
     ap.add_argument("--preset", default="", choices=["", "reference-sweep"],
                     help="reference-sweep: the reference's own benchmark (Source.cpp:627-635): 45 RGB images 1000x1500 ... 7600x11400, "
                          "sigma = sqrt(longer side), one image per call; prints one JSON line with a row per size")
@@ -365,10 +368,16 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item()), tm, per_step
 
+    if args.settle > 0:                                    # untimed, before the contract's W warm-up steps
+        t_end = time.perf_counter() + args.settle
+        while time.perf_counter() < t_end:
+            for _ in range(4):
+                ctx.pffft_(frames, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch, wave_resident=wr, engine=eng)
+            torch.cuda.synchronize(dev)
     elapsed, tm, per_step = timed_run(frames, args.steps, args.warmup, not args.no_events)
     natural = None
     if args.data == "synthetic" and not args.no_natural:
-        nat_elapsed, _, _ = timed_run(make_frames("natural"), args.steps, 2, False)
+        nat_elapsed, _, _ = timed_run(make_frames("natural"), args.steps, max(args.warmup, 10), False)
         natural = nat_elapsed
     # the same workload on the FFT kernels (the path north_star describes), a shorter run, for the record
     fft_value = None
@@ -421,6 +430,7 @@ def main():
                 "sharding": "frames over ranks, no data-path collective",
             },
             "ms_per_step_gpu": percentiles(per_step),       # rank 0, HIP events around every step
+            "settle_s": args.settle,                        # untimed run of the same workload before the W warm-up steps
         }
         if natural is not None:
             rec["value_natural"] = round(mp_total / natural, 1)      # same workload on natural-image frames (tests/golden crop, tiled)

@@ -138,7 +138,11 @@ __device__ __forceinline__ void mx_row_issue(MxRowRaw<NKB>& raw, const uint8_t* 
     const uint8_t* img = src + static_cast<size_t>(f) * g.rows * g.cols * 3;
     const int row = tid >> 3, g0 = tid & 7;
     const int r = mx_refl(r0 + row, g.rows);
+#ifdef MX_ROW_NOQLOAD
+    raw.q = 1.f;
+#else
     if (qrow && tid < 96) raw.q = qrow[(static_cast<size_t>(f) * g.rows + mx_refl(r0 + (tid & 31), g.rows)) * 3 + (tid >> 5)];
+#endif
     // interior unit (uniform): every group is whole, inside the image and dword aligned -> branch-free loads the compiler
     // can issue back to back; otherwise per-pixel reflect-101 (the two edge chunks of a row, odd widths)
     const bool interior = g.aligned && x0 - R::PADA >= 0 && x0 + kMxRowChunk + R::PADA <= g.cols;
@@ -216,10 +220,17 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
         th[kb] = frags[kb * 64 + lane];
         tl[kb] = frags[(NKB + kb) * 64 + lane];
     }
+    // Workgroups b and b + 8 run on the same XCD and share its L2.  Give every XCD a contiguous band of units (units are
+    // numbered chunk-fastest), so that the chunks left and right of a unit -- which read 2 PADA of its 128 + 2 PADA window
+    // columns -- are the same XCD's work at about the same time: without this the window overlap was fetched from memory
+    // 2.5 times (PMC: 489 MB read for 199 MB of frames, profiles/r02mx_pmc_counters.json).
+    const int xcd = blockIdx.x & 7, per_xcd = (nunits + 7) / 8, lanes_x = (gridDim.x + 7 - xcd) / 8;     // workgroups of this XCD
+    const int ubeg = xcd * per_xcd, uend = min(nunits, ubeg + per_xcd);
     MxRowRaw<NKB> raw;
-    int u = blockIdx.x;
-    if (u < nunits) mx_row_issue<NKB>(raw, src, g, u, chunks, rblocks, tid, QUIRK ? qrow : nullptr);
-    for (; u < nunits; u += gridDim.x) {
+    int u = ubeg + (blockIdx.x >> 3);
+    const int ustep = lanes_x;
+    if (u < uend) mx_row_issue<NKB>(raw, src, g, u, chunks, rblocks, tid, QUIRK ? qrow : nullptr);
+    for (; u < uend; u += ustep) {
         const int xc = u % chunks, rb = (u / chunks) % rblocks, f = u / (chunks * rblocks);
         const int x0 = xc * kMxRowChunk, r0 = rb * 32;                 // r0: row of V
         mx_row_commit<NKB>(raw, in, tid);
@@ -228,7 +239,7 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
         __syncthreads();
         // the next unit's pixels travel while this one is in the matrix cores
 #ifndef MX_ROW_NOLOAD
-        if (u + static_cast<int>(gridDim.x) < nunits) mx_row_issue<NKB>(raw, src, g, u + gridDim.x, chunks, rblocks, tid, QUIRK ? qrow : nullptr);
+        if (u + ustep < uend) mx_row_issue<NKB>(raw, src, g, u + ustep, chunks, rblocks, tid, QUIRK ? qrow : nullptr);
 #endif
         // ---- 4 tiles of 32 outputs x 3 channels = 12 products, 3 per wave
         mx_float16 acc[3];
@@ -255,7 +266,12 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
             const int t = wave + 4 * tt, c = t % 3, tile = t / 3;
             const float sgn = (m & 1) ? -1.f : 1.f;                      // x = x0 + 32 tile + m: its parity is m's
             float qv[16];
+#ifdef MX_ROW_NOQLDS
+            if (QUIRK) for (int k = 0; k < 16; ++k) qv[k] = 1.f;
+            if (false) {
+#else
             if (QUIRK) {
+#endif
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float4 t4 = *reinterpret_cast<const float4*>(qs + c * 32 + 8 * k + 4 * h);

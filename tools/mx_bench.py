@@ -26,8 +26,8 @@ g = torch.Generator(device="cuda").manual_seed(1)
 frames = torch.randint(0, 256, (nf, rows, cols, 3), dtype=torch.uint8, device="cuda", generator=g)
 out = torch.empty_like(frames)
 for eng in (("matrix",) if only else ("matrix", "fft")):
-    for quirk in (True, False):
-        for _ in range(3):
+    for quirk in (True, False, True):
+        for _ in range(10):
             ctx.pffft_(frames, sigma, out=out, nyquist_quirk=quirk, engine=eng, frames_per_launch=fpl)
         torch.cuda.synchronize()
         ctx.timing_enable(True)
