@@ -1043,7 +1043,20 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     // an error;  1 / 2 / 5 the FFT kernels (1 never wave-resident, 2 wave-resident wherever it fits, 5 the measured FFT policy below).
     const int choice = opts ? opts->reserved[3] : 0;
     // (allow_wr = false: the caller wants the rows-first float planes themselves, blur_rowpass_u8c3_dev)
-    if (allow_fast && allow_wr && (choice == 0 || choice == 3)) {
+    // Small frames: the matrix-core path is five launches (three for the quirk's pre-pass) against two, and one small frame
+    // does not fill the chip either way, so below 1 MP the library's own choice stays with the FFT kernels WHEN they have a
+    // compile-time family for both passes (the run-time-planned kernels are 3-4 times slower: then the matrix cores win
+    // again).  The choice depends on the frame only, never on the number of frames: a frame blurred alone and the same
+    // frame inside a batch give the same bytes.  (One frame per call, us: 1080p sigma 20 92 matrix / 72 FFT, 4K 147 / 150;
+    // eight frames per call: 1080p 24 / 37 per frame, 4K 74 / 104.)
+    bool small_fft = false;
+    if (choice == 0 && static_cast<long long>(rows) * cols < 1000000ll) {
+        const WrEntry* wc = find_wr_entry(rows + 2 * p.sz.pad, true);
+        const WrEntry* wr = find_wr_entry(cols + 2 * p.sz.pad, false);
+        small_fft = (wc && wr && wc->col_lds(rows) <= kLdsLimit && wr->row_lds(cols) <= kLdsLimit) ||
+                    (find_fast_entry(p.sz.n_col, true) && find_fast_entry(p.sz.n_row, false));
+    }
+    if (allow_fast && allow_wr && !small_fft && (choice == 0 || choice == 3)) {
         const MxEntry* me = find_mx_entry(p.sz.pad);
         const int vpitch = (3 * cols + 31) & ~31;
         const bool fits = me && static_cast<long long>(mx_vrows(rows, me->nkb)) * vpitch < (1ll << 30) && static_cast<long long>(rows) * cols * 3 < (1ll << 32);
@@ -1442,7 +1455,7 @@ static int run_mx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         { TimedLaunch t(ctx, 0, nf);
           HIP_TRY(ctx, p.mx->row_u8(ctx->stream, s, ctx->work, p.mxt->frags_row, g, ctx->num_cus, qrow)); }
         { TimedLaunch t(ctx, 1, nf);
-          HIP_TRY(ctx, p.mx->col_u8(ctx->stream, ctx->work, d, p.mxt->frags_col, g, qcol)); }
+          HIP_TRY(ctx, p.mx->col_u8(ctx->stream, ctx->work, d, p.mxt->frags_col, g, qcol, ctx->num_cus)); }
     }
     return BLUR_OK;
 }

@@ -339,7 +339,7 @@ constexpr uint32_t kMxRsrcWord3 = 0x00020000u;   // raw buffer, 32-bit data form
 #endif
 template <int NKB, bool QUIRK>
 __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* __restrict__ V, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, MxGeom g,
-                                                        int nstrips, const float* __restrict__ qcol)
+                                                        int nstrips, const float* __restrict__ qcol, int tps, int nseg)
 {
     // one wave per SIMD (512 registers): 2 NKB fragments + NACC accumulator tiles + a queue of PD blocks in flight
 #ifdef MX_COL_PD
@@ -349,8 +349,13 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
     constexpr int NACC = (NKB + 1) / 2, PD = (2 * NACC) % 4 == 0 ? 4 : ((2 * NACC) % 3 == 0 ? 3 : 2);
 #endif
     const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
+    // task = (frame, strip, segment): few frames of a small image would leave most of the chip idle with one wave per strip,
+    // so a strip is cut into `nseg` segments of `tps` output tiles (tps a multiple of NACC: the accumulator rotation below
+    // starts aligned).  A segment begins with its own first window block (no run-in) and ends (NKB - 1) / 2 periods after
+    // its last tile's first block: that tail is the only work done twice.
     const int task = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int f = task / nstrips, s = task - f * nstrips;
+    const int seg = task % nseg, fs = task / nseg;
+    const int f = fs / nstrips, s = fs - f * nstrips;
     if (f >= g.nframes) return;
     const int e = 32 * s + n;
     const bool valid = e < 3 * g.cols;
@@ -411,17 +416,18 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
     };
     float queue[PD][QW];
 #endif
+    const int ntiles = (g.rows + 31) / 32;
+    const int tile0 = seg * tps, tile1 = min(tile0 + tps, ntiles);             // this segment's output tiles
 #pragma unroll
-    for (int k = 0; k < PD; ++k) load_block(k, queue[k]);
+    for (int k = 0; k < PD; ++k) load_block(2 * tile0 + k, queue[k]);
 
     mx_float16 acc[NACC];
     const mx_float16 zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = zero;
-    const int ntiles = (g.rows + 31) / 32;
-    const int nperiods = ntiles + (NKB - 1) / 2;
+    const int pend = tile1 + (NKB - 1) / 2;
 
-    for (int mp = 0; mp < nperiods; mp += NACC) {
+    for (int mp = tile0; mp < pend; mp += NACC) {
 #pragma unroll
         for (int q = 0; q < NACC; ++q) {
             const int p = mp + q;
@@ -468,7 +474,8 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
                     // bounds check drops them -- no branch, so the whole period stays one scheduling region)
                     const int a = (NKB - 1 - b) / 2, slot = (q - a + 2 * NACC) % NACC, tile = p - a;
                     {
-                        const uint32_t orow0 = 32u * static_cast<uint32_t>(tile) * rowbytes;        // uniform; tile < 0 wraps far out of bounds
+                        // uniform; a tile outside the segment (accumulators of the run-out, or not yet complete) gets an offset out of bounds
+                        const uint32_t orow0 = (tile >= tile0 && tile < tile1) ? 32u * static_cast<uint32_t>(tile) * rowbytes : 0xfff00000u;
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
                             const float v = __builtin_fmaf(acc[slot][reg], kMxUnscale, (reg & 1) ? cneg : cpos);
@@ -668,7 +675,7 @@ __global__ __launch_bounds__(256) void mx_quirk_terms(const int* __restrict__ sr
 struct MxEntry {
     int nkb;          // window blocks: pad <= 8 (nkb - 2)
     hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus, const float* qrow);
-    hipError_t (*col_u8)(hipStream_t, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qcol);
+    hipError_t (*col_u8)(hipStream_t, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qcol, int num_cus);
 };
 
 template <int NKB> hipError_t mx_launch_row_u8(hipStream_t st, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus, const float* qrow)
@@ -694,14 +701,20 @@ template <int NKB> hipError_t mx_launch_row_u8(hipStream_t st, const uint8_t* sr
     return hipGetLastError();
 }
 
-template <int NKB> hipError_t mx_launch_col_u8(hipStream_t st, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qcol)
+template <int NKB> hipError_t mx_launch_col_u8(hipStream_t st, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qcol, int num_cus)
 {
-    const int nstrips = g.vpitch / 32;
-    const long long tasks = static_cast<long long>(nstrips) * g.nframes;
-    if (tasks <= 0) return hipSuccess;
+    constexpr int NACC = (NKB + 1) / 2;
+    const int nstrips = g.vpitch / 32, ntiles = (g.rows + 31) / 32;
+    const long long strips = static_cast<long long>(nstrips) * g.nframes;
+    if (strips <= 0) return hipSuccess;
+    // segments per strip: as few as fill the chip's 4 waves per CU about once (every segment repeats (NKB - 1) / 2 periods)
+    int tps = ((ntiles + NACC - 1) / NACC) * NACC;
+    while (tps > NACC && strips * ((ntiles + tps - 1) / tps) < 4ll * num_cus) tps -= NACC;
+    const int nseg = (ntiles + tps - 1) / tps;
+    const long long tasks = strips * nseg;
     const dim3 grid(static_cast<unsigned>((tasks + 3) / 4));
-    if (qcol) hipLaunchKernelGGL((mx_colpass_u8<NKB, true>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qcol);
-    else hipLaunchKernelGGL((mx_colpass_u8<NKB, false>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qcol);
+    if (qcol) hipLaunchKernelGGL((mx_colpass_u8<NKB, true>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qcol, tps, nseg);
+    else hipLaunchKernelGGL((mx_colpass_u8<NKB, false>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qcol, tps, nseg);
     return hipGetLastError();
 }
 

@@ -63,9 +63,11 @@ def test_every_instantiated_window(ctx, sigma, nkb):
         assert_u8_parity(got, want, planes)
 
 
-def test_wider_kernels_and_signed_taps_fall_back_to_the_fft_kernels(ctx):
-    """pad > 168 has no matrix-core kernel; a kernel with negative taps does not fit the 24-bit intermediate: the
-    library's own choice is then the FFT engine, and asking for the matrix engine explicitly is an error"""
+def test_the_librarys_choice_of_engine(ctx):
+    """blur_opts.reserved[3] = 0: the matrix-core kernels for frames of 1 MP and more whose kernel they can hold; the FFT
+    kernels for pad > 168, for kernels with negative taps (the 24-bit intermediate does not hold them) and for small frames
+    where the FFT engine has a compile-time family (fewer launches).  The choice never depends on the number of frames.
+    Asking for the matrix engine explicitly where it cannot run is an error."""
     import ctypes as C
     import blur_algorithms_amd as B
     from blur_algorithms_amd.api import BlurError
@@ -73,19 +75,26 @@ def test_wider_kernels_and_signed_taps_fall_back_to_the_fft_kernels(ctx):
     lib = B._lib.load()
     lib.blur_debug_last_family.argtypes = [C.c_void_p]
     lib.blur_debug_last_family.restype = C.c_int
-    img = torch.from_numpy(_rand_img(400, 420, 1)).cuda()
-    ctx.pffft_(img.clone(), 60.0)
-    assert lib.blur_debug_last_family(ctx._h) != 4
-    ctx.pffft_(img.clone(), 20.0)
-    assert lib.blur_debug_last_family(ctx._h) == 4
+    fam = lambda: lib.blur_debug_last_family(ctx._h)
+    batch = torch.zeros((8, 1080, 1920, 3), dtype=torch.uint8, device="cuda")
+    big = torch.zeros((3000, 4100, 3), dtype=torch.uint8, device="cuda")
+    small = torch.from_numpy(_rand_img(400, 420, 1)).cuda()
+    ctx.pffft_(batch, 20.0)
+    assert fam() == 4
+    ctx.pffft_(batch, 60.0)                                       # pad 195
+    assert fam() != 4
     with pytest.raises(BlurError):
-        ctx.pffft_(img.clone(), 60.0, engine="matrix")
-    sharpen = np.array([-0.25, 1.5, -0.25], np.float32)          # symmetric, sum 1, negative side taps
-    ctx.separable(img.clone(), sharpen)
-    assert lib.blur_debug_last_family(ctx._h) != 4
-    smooth = np.array([0.25, 0.5, 0.25], np.float32)
-    ctx.separable(img.clone(), smooth)
-    assert lib.blur_debug_last_family(ctx._h) == 4
+        ctx.pffft_(batch, 60.0, engine="matrix")
+    ctx.pffft_(small.clone(), 20.0)                               # 0.17 MP, wave-resident FFT kernels exist for 530 x 550 points
+    assert fam() == 2
+    ctx.pffft_(batch[0], 20.0)                                    # one frame of the batch: the same engine as the batch
+    assert fam() == 4
+    ctx.pffft_(small.clone(), 20.0, engine="matrix")
+    assert fam() == 4
+    ctx.separable(big, np.array([0.25, 0.5, 0.25], np.float32))
+    assert fam() == 4
+    ctx.separable(big, np.array([-0.25, 1.5, -0.25], np.float32))  # symmetric, sum 1, negative side taps
+    assert fam() != 4
 
 
 def test_matrix_engine_extreme_images(ctx):
