@@ -111,3 +111,46 @@ def test_matrix_engine_extreme_images(ctx):
         want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=True, want_planes=True)
         got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, engine="matrix").cpu().numpy()
         assert_u8_parity(got, want, planes), name
+
+
+def test_matrix_engine_fuzz_time_boxed(ctx):
+    """random shapes (odd widths: the per-byte load path; widths below one chunk; heights below one tile), random sigma over
+    every window size, both quirk settings, uniform and 0 / 255 images, in place and out of place, against the float64
+    oracle; with redzones around the image buffers.  About 30 s."""
+    import time
+    from oracle import oracle as O
+    torch = _torch()
+    rng = np.random.default_rng(20261004)
+    t_end = time.time() + 30.0
+    cases = 0
+    while time.time() < t_end or cases < 15:
+        sigma = float(rng.choice([0.7, 1.5, 3.0, 6.0, 9.5, 14.0, 20.0, 25.0, 30.0, 38.0, 44.0, 50.0]))
+        pad = O.pffft_sizing(4096, 4096, sigma)["pad"]
+        rows = int(rng.integers(pad + 1, pad + 260))
+        cols = int(rng.integers(pad + 1, pad + 420))
+        if rng.random() < 0.4:
+            cols = (cols + 3) & ~3                                   # the aligned 12-byte group path
+        if O.pffft_sizing(rows, cols, sigma)["pad"] > min(rows, cols) - 1:
+            continue
+        quirk = bool(rng.integers(0, 2))
+        kind = rng.choice(["uniform", "binary"])
+        img = rng.integers(0, 256, (rows, cols, 3), dtype=np.uint8) if kind == "uniform" else (rng.integers(0, 2, (rows, cols, 3)) * 255).astype(np.uint8)
+        want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk, want_planes=True)
+        guard = 4096
+        n = rows * cols * 3
+        buf = torch.full((2 * n + 3 * guard,), 0xA5, dtype=torch.uint8, device="cuda")
+        src = buf[guard:guard + n].view(rows, cols, 3)
+        dst = buf[2 * guard + n:2 * guard + 2 * n].view(rows, cols, 3)
+        src.copy_(torch.from_numpy(img))
+        inplace = rng.random() < 0.3
+        got = ctx.pffft_(src, sigma, out=src if inplace else dst, nyquist_quirk=quirk, engine="matrix").cpu().numpy()
+        try:
+            assert_u8_parity(got, want, planes)
+            red = torch.cat([buf[:guard], buf[guard + n:2 * guard + n], buf[2 * guard + 2 * n:]])
+            assert int((red != 0xA5).sum()) == 0, "redzone overwritten"
+            if not inplace:
+                assert np.array_equal(src.cpu().numpy(), img), "source modified"
+            assert ctx._lib.blur_debug_check_workspace_guards(ctx._h) == 0, "workspace guard overwritten"
+        except AssertionError as e:
+            raise AssertionError("rows=%d cols=%d sigma=%r quirk=%d kind=%s inplace=%d: %s" % (rows, cols, sigma, quirk, kind, inplace, e))
+        cases += 1
