@@ -1406,25 +1406,28 @@ int blur_ctx_timing(blur_ctx* ctx, double out_ms[2], int out_launches[2], int ou
     return BLUR_OK;
 }
 
-// both passes on the matrix cores; V (f32, row pitch a multiple of 32 floats) lives in the float workspace
+// both passes on the matrix cores; V (24-bit fixed point, mx_kernels.hpp) lives in the float workspace
 static int run_mx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes, int rows, int cols, int chunk, const Prepared& p)
 {
     const size_t px = static_cast<size_t>(rows) * cols;
     MxGeom g{ rows, cols, p.sz.pad, p.mx_vpitch, 0, 0, mx_vrows(rows, p.mx->nkb) };
-    // ints per frame: Srow [rows][3], A [3 cols], and the partial sums of mx_altsums (nsp per row, nap per column element)
-    const int nsp = 4 * ((cols + kMxAltCols - 1) / kMxAltCols), nap = (rows + kMxAltRows - 1) / kMxAltRows;
-    const size_t sums_per_frame = (static_cast<size_t>(rows) * (1 + nsp) + static_cast<size_t>(cols) * (1 + nap)) * 3;
-    const size_t terms_per_frame = static_cast<size_t>(rows) * 3 + p.mx_vpitch;                // floats: qrow [rows][3], qcol [vpitch]
+    const int chunks = (cols + kMxRowChunk - 1) / kMxRowChunk, rblocks = g.vrows / 32, zblocks = (g.vrows + 255) / 256;
+    // the quirk's scratch per frame: spart int [chunks][rows][3]; then floats: vpart [rblocks][vpitch], qrow [3][vrows], qcol [vpitch];
+    // then doubles: zpart [zblocks][3]
+    const size_t n_spart = static_cast<size_t>(chunks) * rows * 3, n_vpart = static_cast<size_t>(rblocks) * g.vpitch,
+                 n_qrow = static_cast<size_t>(3) * g.vrows, n_qcol = g.vpitch, n_zpart = static_cast<size_t>(zblocks) * 3;
+    const size_t sums_bytes = n_spart * sizeof(int) * chunk;
+    const size_t terms_bytes = ((n_vpart + n_qrow + n_qcol) * sizeof(float) + n_zpart * sizeof(double)) * chunk + 64;
     if (p.mx_quirk) {
-        if (ctx->mx_sums_bytes < sums_per_frame * chunk * sizeof(int)) {
+        if (ctx->mx_sums_bytes < sums_bytes) {
             if (ctx->mx_sums) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->mx_sums)); ctx->mx_sums = nullptr; ctx->mx_sums_bytes = 0; }
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mx_sums), sums_per_frame * chunk * sizeof(int)));
-            ctx->mx_sums_bytes = sums_per_frame * chunk * sizeof(int);
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mx_sums), sums_bytes));
+            ctx->mx_sums_bytes = sums_bytes;
         }
-        if (ctx->mx_terms_bytes < terms_per_frame * chunk * sizeof(float)) {
+        if (ctx->mx_terms_bytes < terms_bytes) {
             if (ctx->mx_terms) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->mx_terms)); ctx->mx_terms = nullptr; ctx->mx_terms_bytes = 0; }
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mx_terms), terms_per_frame * chunk * sizeof(float)));
-            ctx->mx_terms_bytes = terms_per_frame * chunk * sizeof(float);
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mx_terms), terms_bytes));
+            ctx->mx_terms_bytes = terms_bytes;
         }
     }
     for (int f = 0; f < nframes; f += chunk) {
@@ -1433,29 +1436,27 @@ static int run_mx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         uint8_t* d = d_dst + static_cast<size_t>(f) * px * 3;
         g.nframes = nf;
         g.aligned = ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(s) & 3) == 0) ? 1 : 0;
-        const float *qrow = nullptr, *qcol = nullptr;
+        int* spart = nullptr;
+        float *vpart = nullptr, *qrow = nullptr, *qcol = nullptr;
+        double* zpart = nullptr;
         if (p.mx_quirk) {
-            int* srow = ctx->mx_sums;
-            int* asum = srow + static_cast<size_t>(nf) * rows * 3;
-            int* spart = asum + static_cast<size_t>(nf) * cols * 3;
-            int* apart = spart + static_cast<size_t>(nf) * nsp * rows * 3;
-            float* tr = ctx->mx_terms;
-            float* tc = ctx->mx_terms + static_cast<size_t>(nf) * rows * 3;
-            hipLaunchKernelGGL(mx_altsums, dim3(nsp / 4, nap, nf), dim3(256), 0, ctx->stream, s, spart, apart, g);
-            HIP_TRY(ctx, hipGetLastError());
-            hipLaunchKernelGGL(mx_altsums_reduce, dim3((3 * (rows + cols) + 255) / 256, nf), dim3(256), 0, ctx->stream, spart, apart, srow, asum, g, nsp, nap);
-            HIP_TRY(ctx, hipGetLastError());
-            const int rbk = (3 * rows + 255) / 256, cbk = (cols + 255) / 256;
-            hipLaunchKernelGGL(mx_quirk_terms, dim3(rbk + cbk, nf), dim3(256), static_cast<size_t>(256 + 2 * p.sz.pad) * 3 * sizeof(int), ctx->stream, srow, asum,
-                               p.mxt->taps_row, p.mxt->dr, p.mxt->dc, tr, tc, g, rbk);
-            HIP_TRY(ctx, hipGetLastError());
-            qrow = tr;
-            qcol = tc;
+            spart = ctx->mx_sums;
+            zpart = reinterpret_cast<double*>(ctx->mx_terms);                      // doubles first: 8-byte aligned
+            vpart = reinterpret_cast<float*>(zpart + n_zpart * nf);
+            qrow = vpart + n_vpart * nf;
+            qcol = qrow + n_qrow * nf;
         }
         { TimedLaunch t(ctx, 0, nf);
-          HIP_TRY(ctx, p.mx->row_u8(ctx->stream, s, ctx->work, p.mxt->frags_row, g, ctx->num_cus, qrow)); }
+          HIP_TRY(ctx, p.mx->row_u8(ctx->stream, s, ctx->work, p.mxt->frags_row, g, ctx->num_cus, spart, vpart)); }
+        if (p.mx_quirk) {
+            // the Nyquist-slot terms from the row kernel's partial sums: two small launches between the passes
+            hipLaunchKernelGGL(mx_quirk_rows, dim3(zblocks, nf), dim3(256), 0, ctx->stream, spart, qrow, zpart, g, chunks, 8 * (p.mx->nkb - 2), p.mxt->dr);
+            HIP_TRY(ctx, hipGetLastError());
+            hipLaunchKernelGGL(mx_quirk_cols, dim3((g.vpitch + 255) / 256, nf), dim3(256), 0, ctx->stream, vpart, zpart, qcol, g, rblocks, zblocks, p.mxt->dr, p.mxt->dc);
+            HIP_TRY(ctx, hipGetLastError());
+        }
         { TimedLaunch t(ctx, 1, nf);
-          HIP_TRY(ctx, p.mx->col_u8(ctx->stream, ctx->work, d, p.mxt->frags_col, g, qcol, ctx->num_cus)); }
+          HIP_TRY(ctx, p.mx->col_u8(ctx->stream, ctx->work, d, p.mxt->frags_col, g, qcol, ctx->num_cus, qrow)); }
     }
     return BLUR_OK;
 }

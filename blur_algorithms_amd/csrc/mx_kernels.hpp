@@ -38,17 +38,17 @@ constexpr int kMxRowChunk = 128;        // pixels per row-pass unit
 constexpr int kMxStagePitch = 392;      // floats per staged row (384 + 8: the two half-waves land in disjoint banks)
 constexpr float kMxUnscale = 1.f / 16384.f;   // 2^-kMxScaleLog2 (host_math.hpp)
 
-// The intermediate V between the two kernels is 24-bit fixed point: q = round((v + 256) * 2^14), three bytes per value.
-// Range [-256, 512): the taps are non-negative with sum <= 1 (the engine refuses other kernels), so the row pass gives
-// 0..255, and the row pass's quirk term adds at most +-255 (an image alternating 0 / 255 per column); resolution 6.1e-5 grey
-// levels, i.e. a uniform error of at most 3.1e-5 that the column pass averages over ~70 rows.  A quarter less traffic on
-// the 12 of every 15 B/px that are V.  Layout: [frame][strip of 32 values of a V row][group of 8 rows][lane 0..31][24 bytes]
+// The intermediate V between the two kernels is 24-bit fixed point: q = round(v * 2^16), three bytes per value.  Range
+// [0, 256): the taps are non-negative with sum <= 1 (the engine refuses other kernels), so the row pass gives 0..255.13;
+// resolution 1.5e-5 grey levels, i.e. a uniform error of at most 7.6e-6 that the column pass averages over ~70 rows.
+// (The row pass's quirk term, up to +-255, is added by the column pass when it decodes V.)  A quarter less traffic on the
+// 12 of every 15 B/px that are V.  Layout: [frame][strip of 32 values of a V row][group of 8 rows][lane 0..31][24 bytes]
 // -- the 24 bytes are the lane's 8 consecutive rows, exactly its B-operand fragment of the column pass: two loads per
 // 16-row block instead of eight, 768 contiguous bytes per (strip, row group).
 #ifndef MX_V24
 #define MX_V24 1
 #endif
-constexpr float kMxV24Scale = 16384.f, kMxV24Offset = 256.f;
+constexpr float kMxV24Scale = 65536.f, kMxV24Offset = 0.f;
 struct __attribute__((packed, aligned(8))) MxV24x8 { uint32_t d[6]; };
 
 __device__ __forceinline__ MxV24x8 mx_v24_pack(const float (&v)[8])
@@ -125,12 +125,10 @@ __device__ __forceinline__ uint32_t mx_pk(float a, float b)
 template <int NKB> struct MxRowRaw {
     static constexpr int PADA = 8 * (NKB - 2), WIN = kMxRowChunk + 2 * PADA, GPR = WIN / 4, PER = (GPR + 7) / 8;
     uint32_t d[PER][3];
-    float q;            // the quirk's term of (row tid & 31, channel tid >> 5) of the unit, threads 0..95 (QUIRK kernels)
 };
 
 template <int NKB>
-__device__ __forceinline__ void mx_row_issue(MxRowRaw<NKB>& raw, const uint8_t* __restrict__ src, const MxGeom& g, int u, int chunks, int rblocks, int tid,
-                                             const float* __restrict__ qrow)
+__device__ __forceinline__ void mx_row_issue(MxRowRaw<NKB>& raw, const uint8_t* __restrict__ src, const MxGeom& g, int u, int chunks, int rblocks, int tid)
 {
     using R = MxRowRaw<NKB>;
     const int xc = u % chunks, rb = (u / chunks) % rblocks, f = u / (chunks * rblocks);
@@ -138,11 +136,6 @@ __device__ __forceinline__ void mx_row_issue(MxRowRaw<NKB>& raw, const uint8_t* 
     const uint8_t* img = src + static_cast<size_t>(f) * g.rows * g.cols * 3;
     const int row = tid >> 3, g0 = tid & 7;
     const int r = mx_refl(r0 + row, g.rows);
-#ifdef MX_ROW_NOQLOAD
-    raw.q = 1.f;
-#else
-    if (qrow && tid < 96) raw.q = qrow[(static_cast<size_t>(f) * g.rows + mx_refl(r0 + (tid & 31), g.rows)) * 3 + (tid >> 5)];
-#endif
     // interior unit (uniform): every group is whole, inside the image and dword aligned -> branch-free loads the compiler
     // can issue back to back; otherwise per-pixel reflect-101 (the two edge chunks of a row, odd widths)
     const bool interior = g.aligned && x0 - R::PADA >= 0 && x0 + kMxRowChunk + R::PADA <= g.cols;
@@ -176,15 +169,47 @@ __device__ __forceinline__ void mx_row_issue(MxRowRaw<NKB>& raw, const uint8_t* 
 }
 
 // deinterleave + u8 -> binary16 + write to the LDS window [c][row][PW]
-template <int NKB> __device__ __forceinline__ void mx_row_commit(const MxRowRaw<NKB>& raw, _Float16* in, int tid)
+// weight of element i of a line of `len` elements in the alternating sum of its reflect-101 padded line (see the quirk notes below)
+__device__ __forceinline__ int mx_alt_weight(int i, int len, int pad)
+{
+    const int w = 1 + ((i >= 1 && i <= pad) ? 1 : 0) + ((i >= len - 1 - pad && i <= len - 2) ? 1 : 0);
+    return ((i + pad) & 1) ? -w : w;
+}
+
+// sum over the 8 lanes that share a row (lane & 7 = group index): quad xor 1, quad xor 2, then the mirror of the 8-lane half
+__device__ __forceinline__ float mx_sum8(float v)
+{
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xb1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4e, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    return v;
+}
+
+// deinterleave + u8 -> binary16 + write to the LDS window [c][row][PW].  QUIRK: also the alternating sum of the unit's OWN
+// 128 pixels of the thread's row per channel (weights of mx_alt_weight; exact in float: integers below 2^24), summed over
+// the row's 8 threads: s[c], valid in every lane.  `plain`: no pixel of the unit is mirrored (weights are +-1 by parity).
+template <int NKB, bool QUIRK>
+__device__ __forceinline__ void mx_row_commit(const MxRowRaw<NKB>& raw, _Float16* in, int tid, const MxGeom& g, int x0, bool plain, float (&s)[3])
 {
     using R = MxRowRaw<NKB>;
-    constexpr int PW = mx_row_pitch(NKB);
+    constexpr int PW = mx_row_pitch(NKB), GI0 = R::PADA / 4;          // first group of the unit's own pixels
     const int row = tid >> 3, g0 = tid & 7;
     _Float16* base = in + row * PW + 4 * g0;
+    s[0] = s[1] = s[2] = 0.f;
+    const float flip = (g.pad & 1) ? -1.f : 1.f;
 #pragma unroll
     for (int k = 0; k < R::PER; ++k) {
         if ((R::GPR % 8 == 0) || k < R::PER - 1 || g0 < R::GPR % 8) {
+            const int grp = g0 + 8 * k;
+            const bool own = QUIRK && grp >= GI0 && grp < GI0 + 32;
+            float w[4] = { flip, -flip, flip, -flip };                  // x = x0 + 4 (grp - GI0) + q: (x + pad) & 1 = (q + pad) & 1
+            if (QUIRK && !plain) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int x = x0 + 4 * (grp - GI0) + q;
+                    w[q] = x < g.cols ? static_cast<float>(mx_alt_weight(x, g.cols, g.pad)) : 0.f;
+                }
+            }
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float v[4];
@@ -193,25 +218,30 @@ template <int NKB> __device__ __forceinline__ void mx_row_commit(const MxRowRaw<
                     const int byte = 3 * q + c;
                     v[q] = static_cast<float>((raw.d[k][byte >> 2] >> (8 * (byte & 3))) & 0xffu);
                 }
-                uint2 w;
-                w.x = mx_pk(v[0], v[1]);
-                w.y = mx_pk(v[2], v[3]);
-                *reinterpret_cast<uint2*>(base + c * 32 * PW + 32 * k) = w;
+                if (own) s[c] += (v[0] * w[0] + v[1] * w[1]) + (v[2] * w[2] + v[3] * w[3]);
+                uint2 wd;
+                wd.x = mx_pk(v[0], v[1]);
+                wd.y = mx_pk(v[2], v[3]);
+                *reinterpret_cast<uint2*>(base + c * 32 * PW + 32 * k) = wd;
             }
         }
     }
+    if (QUIRK) { s[0] = mx_sum8(s[0]); s[1] = mx_sum8(s[1]); s[2] = mx_sum8(s[2]); }
 }
 
-// two workgroups per CU while the fragments (16 NKB registers) leave room for them
+// two workgroups per CU while the fragments (16 NKB registers) leave room for them.
+// QUIRK: the kernel also leaves the partial sums the Nyquist-slot terms are made of (no extra pass over the image):
+//   spart[f][chunk][image row][3]   alternating sum of the chunk's 128 pixels of that row (integers, exact)
+//   vpart[f][row block of V][e]     sum over the block's image rows of wy(r) V[r][e] (float; e = 3 x + c, pitch vpitch)
 template <int NKB, bool QUIRK>
 __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const uint8_t* __restrict__ src, float* __restrict__ V, const mx_half8* __restrict__ frags, MxGeom g,
-                                                        int chunks, int rblocks, int nunits, const float* __restrict__ qrow)
+                                                        int chunks, int rblocks, int nunits, int* __restrict__ spart, float* __restrict__ vpart)
 {
-    constexpr int PW = mx_row_pitch(NKB);
+    constexpr int PW = mx_row_pitch(NKB), PADA = 8 * (NKB - 2);
     extern __shared__ __attribute__((aligned(16))) unsigned char mx_lds[];
     _Float16* in = reinterpret_cast<_Float16*>(mx_lds);      // [3][32][PW]
     float* stage = reinterpret_cast<float*>(mx_lds);         // [32][kMxStagePitch], after the MFMAs have read `in`
-    float* qs = reinterpret_cast<float*>(mx_lds + mx_row_lds(NKB));   // [3][32]: the quirk's term of the unit's rows (qrow != nullptr)
+    float* wyv = reinterpret_cast<float*>(mx_lds + mx_row_lds(NKB));   // [32]: wy of the unit's rows, 0 for mirrored rows (QUIRK)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, m = lane & 31, h = lane >> 5;
 
     mx_half8 th[NKB], tl[NKB];
@@ -229,18 +259,28 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
     MxRowRaw<NKB> raw;
     int u = ubeg + (blockIdx.x >> 3);
     const int ustep = lanes_x;
-    if (u < uend) mx_row_issue<NKB>(raw, src, g, u, chunks, rblocks, tid, QUIRK ? qrow : nullptr);
+    if (u < uend) mx_row_issue<NKB>(raw, src, g, u, chunks, rblocks, tid);
     for (; u < uend; u += ustep) {
         const int xc = u % chunks, rb = (u / chunks) % rblocks, f = u / (chunks * rblocks);
         const int x0 = xc * kMxRowChunk, r0 = rb * 32;                 // r0: row of V
-        mx_row_commit<NKB>(raw, in, tid);
-        // Nyquist-slot quirk of the row pass (Source.cpp:420-425): V[r][x] += qrow[r][c] * (-1)^x, qrow = dr (-1)^pad Srow
-        if (QUIRK && tid < 96) qs[tid] = raw.q;
+        // no pixel of the unit's own 128 is a mirror source: weights +-1 (uniform)
+        const bool plain = x0 > g.pad && x0 + kMxRowChunk + g.pad + 1 < g.cols;
+        float s[3];
+        mx_row_commit<NKB, QUIRK>(raw, in, tid, g, x0, plain, s);
+        if (QUIRK) {
+            const int ri = r0 - PADA + (tid >> 3);                     // image row of the thread's row of V; mirrored rows are not counted
+            if ((tid & 7) == 0 && ri >= 0 && ri < g.rows) {
+                int* sp = spart + ((static_cast<size_t>(f) * chunks + xc) * g.rows + ri) * 3;
+                sp[0] = static_cast<int>(s[0]); sp[1] = static_cast<int>(s[1]); sp[2] = static_cast<int>(s[2]);
+            }
+            if (tid < 32) {
+                const int rw = r0 - PADA + tid;
+                wyv[tid] = (rw >= 0 && rw < g.rows) ? static_cast<float>(mx_alt_weight(rw, g.rows, g.pad)) : 0.f;
+            }
+        }
         __syncthreads();
         // the next unit's pixels travel while this one is in the matrix cores
-#ifndef MX_ROW_NOLOAD
-        if (u + ustep < uend) mx_row_issue<NKB>(raw, src, g, u + ustep, chunks, rblocks, tid, QUIRK ? qrow : nullptr);
-#endif
+        if (u + ustep < uend) mx_row_issue<NKB>(raw, src, g, u + ustep, chunks, rblocks, tid);
         // ---- 4 tiles of 32 outputs x 3 channels = 12 products, 3 per wave
         mx_float16 acc[3];
 #pragma unroll
@@ -251,39 +291,40 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb) {
                 const mx_half8 x = *reinterpret_cast<const mx_half8*>(base + 16 * kb);
-#ifdef MX_ROW_NOMFMA
-                if (kb > 0) continue;
-#endif
                 a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, th[kb], a, 0, 0, 0);
                 a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, tl[kb], a, 0, 0, 0);
             }
             acc[tt] = a;
+        }
+        if (QUIRK) {
+            // column sums of the tile: D[row][x] with the lane's 16 rows in registers -> 16 multiply-adds, one exchange with lane ^ 32
+            float wy[16];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 t4 = *reinterpret_cast<const float4*>(wyv + 8 * k + 4 * h);
+                wy[4 * k] = t4.x; wy[4 * k + 1] = t4.y; wy[4 * k + 2] = t4.z; wy[4 * k + 3] = t4.w;
+            }
+            float* vp = vpart + (static_cast<size_t>(f) * rblocks + rb) * g.vpitch;
+#pragma unroll
+            for (int tt = 0; tt < 3; ++tt) {
+                const int t = wave + 4 * tt, c = t % 3, tile = t / 3;
+                float cs = 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) cs = __builtin_fmaf(acc[tt][reg], wy[reg], cs);
+                cs += __shfl_xor(cs, 32);
+                const int e = 3 * (x0 + tile * 32 + m) + c;
+                if (h == 0 && e < g.vpitch) vp[e] = cs * kMxUnscale;
+            }
         }
         __syncthreads();
         // ---- re-interleave through LDS: D[row][o], row = (reg & 3) + 8 (reg >> 2) + 4 h, o = lane & 31
 #pragma unroll
         for (int tt = 0; tt < 3; ++tt) {
             const int t = wave + 4 * tt, c = t % 3, tile = t / 3;
-            const float sgn = (m & 1) ? -1.f : 1.f;                      // x = x0 + 32 tile + m: its parity is m's
-            float qv[16];
-#ifdef MX_ROW_NOQLDS
-            if (QUIRK) for (int k = 0; k < 16; ++k) qv[k] = 1.f;
-            if (false) {
-#else
-            if (QUIRK) {
-#endif
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float4 t4 = *reinterpret_cast<const float4*>(qs + c * 32 + 8 * k + 4 * h);
-                    qv[4 * k] = t4.x; qv[4 * k + 1] = t4.y; qv[4 * k + 2] = t4.z; qv[4 * k + 3] = t4.w;
-                }
-            }
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
-                float v = acc[tt][reg] * kMxUnscale;
-                if (QUIRK) v = __builtin_fmaf(qv[reg], sgn, v);
-                stage[row * kMxStagePitch + (tile * 32 + m) * 3 + c] = v;
+                stage[row * kMxStagePitch + (tile * 32 + m) * 3 + c] = acc[tt][reg] * kMxUnscale;
             }
         }
         __syncthreads();
@@ -298,9 +339,6 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
                     float v[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] = stage[(8 * rgi + j) * kMxStagePitch + 32 * sidx + n];
-#ifdef MX_ROW_NOSTORE
-                    if (v[0] == 12345.678f)
-#endif
                     *reinterpret_cast<MxV24x8*>(vbase + (static_cast<size_t>(strip) * (g.vrows / 8) + (r0 / 8 + rgi)) * 768 + 24 * n) = mx_v24_pack(v);
                 }
             }
@@ -320,7 +358,6 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
 // v - float(hi) for both halves of a packed binary16 pair, one mixed-precision FMA each (hi * -1.0 + v)
 __device__ __forceinline__ void mx_remainder(uint32_t hi2, float v0, float v1, float& r0, float& r1)
 {
@@ -330,24 +367,24 @@ __device__ __forceinline__ void mx_remainder(uint32_t hi2, float v0, float v1, f
 
 constexpr uint32_t kMxRsrcWord3 = 0x00020000u;   // raw buffer, 32-bit data format (gfx9 family)
 
-// QUIRK: out += qcol[f][e] * (-1)^r  (e = 3 x + c): the column pass's Nyquist-slot term; the row pass's is already in V
+// QUIRK: V[re][e] += qrow[f][c][re] * (-1)^x when a block is decoded (the row pass's Nyquist-slot term; qrow is indexed by the
+// row of V, mirrored rows included), and out += qcol[f][e] * (-1)^r (the column pass's term); e = 3 x + c.  The qrow loads
+// ride with the block's data loads -- same place in the in-order vmcnt queue, consumed together
 // All global accesses are buffer instructions: resource = this wave's strip of this frame, vector offset = the lane's
 // constant byte offset, scalar offset = the row -- no vector arithmetic per access, and a store whose offset lies past
 // the image (rows of the last partial tile, columns past 3 cols) is dropped by the bounds check of the resource.
+// two waves per SIMD while 2 NKB fragments + NACC accumulator tiles fit 256 registers without spills (NKB = 11: the metric), then with 2 blocks in flight per
+// wave; one wave per SIMD and 4 blocks otherwise.  Measured for NKB = 11 with the quirk's terms: 30.7 against 32.1 us per frame.
 #ifndef MX_COL_WAVES
-#define MX_COL_WAVES 1
+#define MX_COL_WAVES(NKB_) ((NKB_) == 11 ? 2 : 1)
 #endif
 template <int NKB, bool QUIRK>
-__global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* __restrict__ V, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, MxGeom g,
-                                                        int nstrips, const float* __restrict__ qcol, int tps, int nseg)
+__global__ __launch_bounds__(256, MX_COL_WAVES(NKB)) void mx_colpass_u8(const float* __restrict__ V, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, MxGeom g,
+                                                        int nstrips, const float* __restrict__ qcol, int tps, int nseg, const float* __restrict__ qrow)
 {
-    // one wave per SIMD (512 registers): 2 NKB fragments + NACC accumulator tiles + a queue of PD blocks in flight
-#ifdef MX_COL_PD
-    constexpr int NACC = (NKB + 1) / 2, PD = MX_COL_PD;
-#else
-    // PD blocks of 8 loads + 16 byte stores + 4 term loads stay below the 63 the vmcnt counter can express
-    constexpr int NACC = (NKB + 1) / 2, PD = (2 * NACC) % 4 == 0 ? 4 : ((2 * NACC) % 3 == 0 ? 3 : 2);
-#endif
+    // PD blocks in flight (PD divides the 2 NACC blocks of an unrolled round, so queue slots are compile-time); their loads, the
+    // 16 byte stores of a tile and the quirk's term loads stay below the 63 the vmcnt counter can express
+    constexpr int NACC = (NKB + 1) / 2, PD = MX_COL_WAVES(NKB) == 2 ? 2 : ((2 * NACC) % 4 == 0 ? 4 : ((2 * NACC) % 3 == 0 ? 3 : 2));
     const int lane = threadIdx.x & 63, n = lane & 31, h = lane >> 5;
     // task = (frame, strip, segment): few frames of a small image would leave most of the chip idle with one wave per strip,
     // so a strip is cut into `nseg` segments of `tps` output tiles (tps a multiple of NACC: the accumulator rotation below
@@ -372,7 +409,6 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(strip), 0, g.vrows * vrowbytes - 128u * s, kMxRsrcWord3);
 #endif
     uint8_t* ostrip = dst + static_cast<size_t>(f) * g.rows * rowbytes + 32 * s;                   // uniform
-    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(ostrip, 0, g.rows * rowbytes - 32u * s, kMxRsrcWord3);
 #if MX_V24
     const uint32_t lane_in = 24u * n + 768u * h;                                                   // byte offset inside a block (two row groups)
 #else
@@ -387,10 +423,16 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
         tl[kb] = frags[(NKB + kb) * 64 + lane];
     }
     float cpos = 0.5f, cneg = 0.5f;                      // + 0.5f of the u8 conversion, +- the column term on even / odd rows
+    float sgn_x = 0.f;
+    __amdgpu_buffer_rsrc_t rq = rin;
+    uint32_t lane_q = 0;
     if (QUIRK) {
         const float qc = valid ? qcol[static_cast<size_t>(f) * g.vpitch + e] : 0.f;
         cpos = 0.5f + qc;
         cneg = 0.5f - qc;
+        sgn_x = valid ? (((e / 3) & 1) ? -1.f : 1.f) : 0.f;
+        rq = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(qrow) + static_cast<size_t>(f) * 3 * g.vrows, 0, 12u * g.vrows, kMxRsrcWord3);
+        lane_q = 4u * (static_cast<uint32_t>(e % 3) * g.vrows + 8u * h);                          // the lane's channel, its 8 rows of a block
     }
 
     const int nblocks = g.vrows / 16;
@@ -405,7 +447,15 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
         const u2 b = __builtin_amdgcn_raw_buffer_load_b64(rin, lane_in + 16u, off, 0);
         d[0] = a[0]; d[1] = a[1]; d[2] = a[2]; d[3] = a[3]; d[4] = b[0]; d[5] = b[1];
     };
+    auto load_terms = [&](int jb, float (&q)[8]) {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const uint32_t off = 64u * min(jb, nblocks - 1);                                            // uniform: 16 rows x 4 bytes
+        const f4 a = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rq, lane_q, off, 0));
+        const f4 b = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rq, lane_q + 16u, off, 0));
+        q[0] = a[0]; q[1] = a[1]; q[2] = a[2]; q[3] = a[3]; q[4] = b[0]; q[5] = b[1]; q[6] = b[2]; q[7] = b[3];
+    };
     uint32_t queue[PD][QW];
+    float qqueue[QUIRK ? PD : 1][8];
 #else
     constexpr int QW = 8;
     auto load_block = [&](int jb, float (&v)[8]) {
@@ -418,8 +468,15 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
 #endif
     const int ntiles = (g.rows + 31) / 32;
     const int tile0 = seg * tps, tile1 = min(tile0 + tps, ntiles);             // this segment's output tiles
+    // the output resource covers exactly the segment's rows of the strip: rows of other segments (the incomplete tiles of the
+    // run-in, the repeated ones of the run-out), rows past the image and columns past 3 cols all fail its bounds check
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(ostrip + static_cast<size_t>(32 * tile0) * rowbytes, 0,
+                                                                          static_cast<uint32_t>(min(32 * tile1, g.rows) - 32 * tile0) * rowbytes - 32u * s, kMxRsrcWord3);
 #pragma unroll
-    for (int k = 0; k < PD; ++k) load_block(2 * tile0 + k, queue[k]);
+    for (int k = 0; k < PD; ++k) {
+        load_block(2 * tile0 + k, queue[k]);
+        if (QUIRK) load_terms(2 * tile0 + k, qqueue[k]);
+    }
 
     mx_float16 acc[NACC];
     const mx_float16 zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
@@ -442,6 +499,10 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
                 float vv[8];
 #if MX_V24
                 mx_v24_unpack(queue[slotq], vv);
+                if (QUIRK) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) vv[k] = __builtin_fmaf(qqueue[slotq][k], sgn_x, vv[k]);
+                }
 #else
 #pragma unroll
                 for (int k = 0; k < 8; ++k) vv[k] = queue[slotq][k];
@@ -458,6 +519,7 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
                 }
                 const mx_half8 v1 = __builtin_bit_cast(mx_half8, w1), v2 = __builtin_bit_cast(mx_half8, w2);
                 load_block(2 * p + b + PD, queue[slotq]);
+                if (QUIRK) load_terms(2 * p + b + PD, qqueue[slotq]);
 #pragma unroll
                 for (int a = 0; 2 * a + b < NKB; ++a) {
                     const int d = 2 * a + b, slot = (q - a + 2 * NACC) % NACC;
@@ -474,8 +536,8 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
                     // bounds check drops them -- no branch, so the whole period stays one scheduling region)
                     const int a = (NKB - 1 - b) / 2, slot = (q - a + 2 * NACC) % NACC, tile = p - a;
                     {
-                        // uniform; a tile outside the segment (accumulators of the run-out, or not yet complete) gets an offset out of bounds
-                        const uint32_t orow0 = (tile >= tile0 && tile < tile1) ? 32u * static_cast<uint32_t>(tile) * rowbytes : 0xfff00000u;
+                        // uniform, relative to the segment's first row: tiles before the segment wrap far out of bounds
+                        const uint32_t orow0 = 32u * static_cast<uint32_t>(tile - tile0) * rowbytes;
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
                             const float v = __builtin_fmaf(acc[slot][reg], kMxUnscale, (reg & 1) ? cneg : cpos);
@@ -505,185 +567,80 @@ __global__ __launch_bounds__(256, MX_COL_WAVES) void mx_colpass_u8(const float* 
 //     Scol(x) = sum_t taps[t] A(refl(x + t)) + dr (-1)^(x+pad) Z,   A(x) = sum_r wy(r) img[r][x],  Z = sum_x wx(x) A(x)
 // mx_altsums reads the image once for Srow and A (exact integers: the result does not depend on the order of the
 // additions); mx_quirk_terms turns them into the two float vectors the column kernel adds.
-__device__ __forceinline__ int mx_alt_weight(int i, int len, int pad)
-{
-    const int w = 1 + ((i >= 1 && i <= pad) ? 1 : 0) + ((i >= len - 1 - pad && i <= len - 2) ? 1 : 0);
-    return ((i + pad) & 1) ? -w : w;
-}
 
-// sum over the 64 lanes on the vector ALU (DPP row shifts, then the two row broadcasts): the total is in lane 63.
-// (__shfl_xor is ds_bpermute: eighteen of them per image row made the LDS crossbar this kernel's bottleneck.)
-__device__ __forceinline__ int mx_wave_sum_lane63(int v)
-{
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);    // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);    // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);    // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);    // row_shr:8   -> lane 15 of every row of 16: the row's sum
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);    // row_bcast:15 into rows 1 and 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);    // row_bcast:31 into rows 2 and 3
-    return v;
-}
-
-constexpr int kMxAltRows = 32;       // image rows per block of mx_altsums
-constexpr int kMxAltCols = 1024;     // pixels per block: one group of 4 pixels (12 bytes) per thread
 #ifdef BLUR_MX_QUIRK_KERNELS   // engine.hip only: plain (non-template) kernels must live in one translation unit
-// grid: (column tiles, row blocks, frames).  No atomics: a block writes its partial sums,
-//   spart[f][ct * 4 + wave][r][3]   the wave's 256 pixels of row r       (ct: column tile, 4 waves each)
-//   apart[f][rb][3 cols]            the block's rows of column element e (rb: row block)
-// and mx_altsums_reduce adds the partials up (integers: exact in any order, and no memset per call).
-__global__ __launch_bounds__(256) void mx_altsums(const uint8_t* __restrict__ src, int* __restrict__ spart, int* __restrict__ apart, MxGeom g)
+// Rows: Srow[r][c] = sum over the chunks of spart (integers); qrow[f][c][re] = dr (-1)^pad Srow[refl(re - PADA)][c] for every
+// row re of V; zpart[f][block][c] = the block's part of Z_c = sum_r wy(r) Srow[r][c].  grid: (ceil(vrows / 256), frames)
+__global__ __launch_bounds__(256) void mx_quirk_rows(const int* __restrict__ spart, float* __restrict__ qrow, double* __restrict__ zpart, MxGeom g, int chunks,
+                                                     int pada, float dr)
 {
-    const int f = blockIdx.z, r0 = blockIdx.y * kMxAltRows, tid = threadIdx.x;
-    const int xg = blockIdx.x * kMxAltCols + 4 * tid;
-    const uint8_t* img = src + static_cast<size_t>(f) * g.rows * g.cols * 3;
-    int wx[4], a[12];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) wx[q] = xg + q < g.cols ? mx_alt_weight(xg + q, g.cols, g.pad) : 0;
-#pragma unroll
-    for (int k = 0; k < 12; ++k) a[k] = 0;
-    const bool fast = g.aligned && xg + 3 < g.cols;
-    const int rend = min(r0 + kMxAltRows, g.rows);
-    int* sp = spart + ((static_cast<size_t>(f) * gridDim.x * 4 + blockIdx.x * 4 + (tid >> 6)) * g.rows) * 3;
-    auto fetch = [&](int r, uint32_t (&d)[3]) {
-        d[0] = d[1] = d[2] = 0;
-        if (xg >= g.cols) return;
-        const uint8_t* line = img + (static_cast<size_t>(r) * g.cols + xg) * 3;
-        if (fast) {
-            typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-            const u3 t = *reinterpret_cast<const u3*>(line);
-            d[0] = t[0]; d[1] = t[1]; d[2] = t[2];
-        } else {
-            for (int b = 0; b < 12; ++b)
-                if (xg + b / 3 < g.cols) d[b >> 2] |= static_cast<uint32_t>(line[b]) << (8 * (b & 3));
-        }
-    };
-    for (int rr = r0; rr < rend; rr += 8) {
-        uint32_t d[8][3];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) fetch(min(rr + k, rend - 1), d[k]);       // eight rows in flight
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            const int r = rr + k;
-            if (r >= rend) break;                                              // uniform
-            const int wy = mx_alt_weight(r, g.rows, g.pad);
-            int sr[3] = { 0, 0, 0 };
-#pragma unroll
-            for (int b = 0; b < 12; ++b) {
-                const int v = static_cast<int>((d[k][b >> 2] >> (8 * (b & 3))) & 0xffu);
-                a[b] += wy * v;
-                sr[b % 3] += wx[b / 3] * v;
-            }
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int v = mx_wave_sum_lane63(sr[c]);
-                if ((tid & 63) == 63) sp[3 * r + c] = v;
-            }
-        }
-    }
-    int* ap = apart + (static_cast<size_t>(f) * gridDim.y + blockIdx.y) * 3 * g.cols + 3 * xg;
-#pragma unroll
-    for (int b = 0; b < 12; ++b)
-        if (xg + b / 3 < g.cols) ap[b] = a[b];
-}
-
-// srow[f][r][3] = sum over nsp partials; asum[f][e] = sum over nap partials.  grid: (blocks of 256 over 3 rows + 3 cols, frames)
-__global__ __launch_bounds__(256) void mx_altsums_reduce(const int* __restrict__ spart, const int* __restrict__ apart, int* __restrict__ srow,
-                                                         int* __restrict__ asum, MxGeom g, int nsp, int nap)
-{
-    const int f = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x, ns = 3 * g.rows, na = 3 * g.cols;
-    // (eight independent loads per trip: a serial chain of nap dependent L2 round trips was most of this kernel's time)
-    if (i < ns) {
-        const int* p = spart + static_cast<size_t>(f) * nsp * ns + i;
-        int v = 0, k = 0;
-        for (; k + 8 <= nsp; k += 8) {
-            int t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = p[static_cast<size_t>(k + j) * ns];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v += t[j];
-        }
-        for (; k < nsp; ++k) v += p[static_cast<size_t>(k) * ns];
-        srow[static_cast<size_t>(f) * ns + i] = v;
-    } else if (i - ns < na) {
-        const int e = i - ns;
-        const int* p = apart + static_cast<size_t>(f) * nap * na + e;
-        int v = 0, k = 0;
-        for (; k + 8 <= nap; k += 8) {
-            int t[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) t[j] = p[static_cast<size_t>(k + j) * na];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v += t[j];
-        }
-        for (; k < nap; ++k) v += p[static_cast<size_t>(k) * na];
-        asum[static_cast<size_t>(f) * na + e] = v;
-    }
-}
-
-// grid: (row blocks + column blocks, frames), 256 outputs per block; taps: 2 pad + 1 floats (centre at pad); dynamic LDS:
-// (256 + 2 pad) * 3 ints.  qrow[f][r][c] = dr (-1)^pad Srow_c(r) (the row kernel multiplies it with (-1)^x and adds it to V);
-// qcol[f][e] = dc (-1)^pad Scol(e), e = 3 x + c (the column kernel multiplies it with (-1)^r)
-__global__ __launch_bounds__(256) void mx_quirk_terms(const int* __restrict__ srow, const int* __restrict__ asum, const float* __restrict__ taps_row,
-                                                      float dr, float dc, float* __restrict__ qrow, float* __restrict__ qcol, MxGeom g, int row_blocks)
-{
-    __shared__ double zpart[3][256];
-    extern __shared__ int mx_win[];                               // [window][3]
-    const int f = blockIdx.y, tid = threadIdx.x;
-    const int* sr = srow + static_cast<size_t>(f) * g.rows * 3;
-    const int* as = asum + static_cast<size_t>(f) * 3 * g.cols;
+    __shared__ double zs[3][256];
+    const int f = blockIdx.y, tid = threadIdx.x, re = blockIdx.x * 256 + tid;
     const double sp = (g.pad & 1) ? -1.0 : 1.0;
-    if (static_cast<int>(blockIdx.x) < row_blocks) {
-        const int i = blockIdx.x * 256 + tid;
-        if (i < 3 * g.rows) qrow[static_cast<size_t>(f) * g.rows * 3 + i] = static_cast<float>(static_cast<double>(dr) * sp * sr[i]);
-        return;
-    }
-    // Z_c = sum_x wx(x) A_c(x): every column block computes it (a few thousand integer reads from L2)
     double z[3] = { 0, 0, 0 };
-    for (int x = tid; x < g.cols; x += 256) {
-        const double w = mx_alt_weight(x, g.cols, g.pad);
-        z[0] += w * as[3 * x]; z[1] += w * as[3 * x + 1]; z[2] += w * as[3 * x + 2];
+    if (re < g.vrows) {
+        const int r = mx_refl(re - pada, g.rows);
+        const bool own = re - pada >= 0 && re - pada < g.rows;           // every image row is counted once in Z
+        const int* p = spart + (static_cast<size_t>(f) * chunks * g.rows + r) * 3;
+        int sum[3] = { 0, 0, 0 };
+        for (int k = 0; k < chunks; ++k) {
+            const int* q = p + static_cast<size_t>(k) * g.rows * 3;
+            sum[0] += q[0]; sum[1] += q[1]; sum[2] += q[2];
+        }
+        const double wy = own ? static_cast<double>(mx_alt_weight(r, g.rows, g.pad)) : 0.0;
+        for (int c = 0; c < 3; ++c) {
+            qrow[(static_cast<size_t>(f) * 3 + c) * g.vrows + re] = static_cast<float>(static_cast<double>(dr) * sp * sum[c]);
+            z[c] = wy * sum[c];
+        }
     }
-    for (int c = 0; c < 3; ++c) zpart[c][tid] = z[c];
-    // Scol for 256 pixels (768 values of e, three per thread): their window of A through LDS
-    const int x0 = (blockIdx.x - row_blocks) * 256, wlen = 256 + 2 * g.pad;
-    for (int k = tid; k < wlen; k += 256) {
-        const int x = mx_refl(x0 - g.pad + k, g.cols);
-        mx_win[3 * k] = as[3 * x]; mx_win[3 * k + 1] = as[3 * x + 1]; mx_win[3 * k + 2] = as[3 * x + 2];
-    }
+    for (int c = 0; c < 3; ++c) zs[c][tid] = z[c];
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
-        if (tid < o) for (int c = 0; c < 3; ++c) zpart[c][tid] += zpart[c][tid + o];
+        if (tid < o) for (int c = 0; c < 3; ++c) zs[c][tid] += zs[c][tid + o];
         __syncthreads();
     }
-    const int x = x0 + tid;
-    if (x < g.cols) {
-        double acc[3] = { 0, 0, 0 };
-#pragma unroll 4
-        for (int t = 0; t <= 2 * g.pad; ++t) {
-            const double w = taps_row[t];
-            acc[0] += w * mx_win[3 * (tid + t)]; acc[1] += w * mx_win[3 * (tid + t) + 1]; acc[2] += w * mx_win[3 * (tid + t) + 2];
-        }
-        const double sx = static_cast<double>(dr) * (((x + g.pad) & 1) ? -1.0 : 1.0);
-        for (int c = 0; c < 3; ++c)
-            qcol[static_cast<size_t>(f) * g.vpitch + 3 * x + c] = static_cast<float>(static_cast<double>(dc) * sp * (acc[c] + sx * zpart[c][0]));
-    }
+    if (tid < 3) zpart[(static_cast<size_t>(f) * gridDim.x + blockIdx.x) * 3 + tid] = zs[tid][0];
 }
 
+// Columns: Scol[e] = sum over the row blocks of vpart + dr (-1)^(x+pad) Z_c; qcol[f][e] = dc (-1)^pad Scol[e].
+// grid: (ceil(vpitch / 256), frames)
+__global__ __launch_bounds__(256) void mx_quirk_cols(const float* __restrict__ vpart, const double* __restrict__ zpart, float* __restrict__ qcol, MxGeom g,
+                                                     int rblocks, int zblocks, float dr, float dc)
+{
+    const int f = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.vpitch) return;
+    const int x = e / 3, c = e - 3 * x;
+    double zc = 0;
+    for (int k = 0; k < zblocks; ++k) zc += zpart[(static_cast<size_t>(f) * zblocks + k) * 3 + c];
+    const float* p = vpart + static_cast<size_t>(f) * rblocks * g.vpitch + e;
+    double acc = 0;
+    int k = 0;
+    for (; k + 8 <= rblocks; k += 8) {                       // eight independent loads per trip
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = p[static_cast<size_t>(k + j) * g.vpitch];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc += t[j];
+    }
+    for (; k < rblocks; ++k) acc += p[static_cast<size_t>(k) * g.vpitch];
+    const double sp = (g.pad & 1) ? -1.0 : 1.0, sx = ((x + g.pad) & 1) ? -1.0 : 1.0;
+    qcol[static_cast<size_t>(f) * g.vpitch + e] = x < g.cols ? static_cast<float>(static_cast<double>(dc) * sp * (acc + static_cast<double>(dr) * sx * zc)) : 0.f;
+}
 #endif  // BLUR_MX_QUIRK_KERNELS
 
 // ---- launchers: one translation unit per NKB (mx_conv_<NKB>.hip) --------------------------------------------------
 struct MxEntry {
     int nkb;          // window blocks: pad <= 8 (nkb - 2)
-    hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus, const float* qrow);
-    hipError_t (*col_u8)(hipStream_t, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qcol, int num_cus);
+    hipError_t (*row_u8)(hipStream_t, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus, int* spart, float* vpart);
+    hipError_t (*col_u8)(hipStream_t, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qcol, int num_cus, const float* qrow);
 };
 
-template <int NKB> hipError_t mx_launch_row_u8(hipStream_t st, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus, const float* qrow)
+template <int NKB> hipError_t mx_launch_row_u8(hipStream_t st, const uint8_t* src, float* V, const void* frags, MxGeom g, int num_cus, int* spart, float* vpart)
 {
     const int chunks = (g.cols + kMxRowChunk - 1) / kMxRowChunk, rblocks = g.vrows / 32;
     const long long nunits = static_cast<long long>(chunks) * rblocks * g.nframes;
     if (nunits <= 0) return hipSuccess;
-    const size_t lds = mx_row_lds(NKB) + 96 * sizeof(float);
+    const size_t lds = mx_row_lds(NKB) + 32 * sizeof(float);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mx_rowpass_u8<NKB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
         if (e != hipSuccess) return e;
@@ -692,16 +649,17 @@ template <int NKB> hipError_t mx_launch_row_u8(hipStream_t st, const uint8_t* sr
     }
     const int per_cu = (lds <= 80 * 1024 && NKB <= 17) ? 2 : 1;
     const int grid = static_cast<int>(nunits < static_cast<long long>(num_cus) * per_cu ? nunits : static_cast<long long>(num_cus) * per_cu);
-    if (qrow)
+    if (spart)
         hipLaunchKernelGGL((mx_rowpass_u8<NKB, true>), dim3(grid), dim3(256), lds, st, src, V, static_cast<const mx_half8*>(frags), g, chunks, rblocks,
-                           static_cast<int>(nunits), qrow);
+                           static_cast<int>(nunits), spart, vpart);
     else
         hipLaunchKernelGGL((mx_rowpass_u8<NKB, false>), dim3(grid), dim3(256), lds, st, src, V, static_cast<const mx_half8*>(frags), g, chunks, rblocks,
-                           static_cast<int>(nunits), qrow);
+                           static_cast<int>(nunits), spart, vpart);
     return hipGetLastError();
 }
 
-template <int NKB> hipError_t mx_launch_col_u8(hipStream_t st, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qcol, int num_cus)
+template <int NKB> hipError_t mx_launch_col_u8(hipStream_t st, const float* V, uint8_t* dst, const void* frags, MxGeom g, const float* qcol, int num_cus,
+                                               const float* qrow)
 {
     constexpr int NACC = (NKB + 1) / 2;
     const int nstrips = g.vpitch / 32, ntiles = (g.rows + 31) / 32;
@@ -713,8 +671,8 @@ template <int NKB> hipError_t mx_launch_col_u8(hipStream_t st, const float* V, u
     const int nseg = (ntiles + tps - 1) / tps;
     const long long tasks = strips * nseg;
     const dim3 grid(static_cast<unsigned>((tasks + 3) / 4));
-    if (qcol) hipLaunchKernelGGL((mx_colpass_u8<NKB, true>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qcol, tps, nseg);
-    else hipLaunchKernelGGL((mx_colpass_u8<NKB, false>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qcol, tps, nseg);
+    if (qcol) hipLaunchKernelGGL((mx_colpass_u8<NKB, true>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qcol, tps, nseg, qrow);
+    else hipLaunchKernelGGL((mx_colpass_u8<NKB, false>), grid, dim3(256), 0, st, V, dst, static_cast<const mx_half8*>(frags), g, nstrips, qcol, tps, nseg, qrow);
     return hipGetLastError();
 }
 
