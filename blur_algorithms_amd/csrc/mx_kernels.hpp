@@ -1,6 +1,6 @@
 // mx_kernels.hpp -- the separable blur as two banded Toeplitz products on the f16 matrix cores (gfx950).
 //
-// Why this exists beside the FFT kernels: both FFT families are bound by vector-ALU issue, not by HBM (DESIGN.md §8:
+// Why this exists beside the FFT kernels: both FFT families are bound by vector-ALU issue, not by HBM (DESIGN.md §8.1:
 // 90 % / 68 % VALU busy at 0.26 of the HBM roofline, and the butterfly arithmetic alone is above the 70 % budget).  For
 // the kernel widths the reference is used with (sigma 20: 131 taps) the same linear map
 //
@@ -9,20 +9,22 @@
 //
 // costs 2 x 176 multiply-adds per output as a dense 32 x 176 Toeplitz tile -- 3 % of the chip's f16 MFMA rate -- so the
 // path becomes what SURVEY 8(d) assumed it was: a stream over HBM.  Precision: the u8 image is exact in binary16; the
-// taps are split into hi + lo halves (22 significant bits); the f32 intermediate is split into hi + lo halves when the
-// column pass loads it; products are exact in the f32 accumulators of v_mfma_f32_32x32x16_f16.  The Nyquist-slot quirk
-// of pffft_() (Source.cpp:420-425) is a rank-one term per line and is added from the exact integer alternating sums of
-// the image (mx_altsums / mx_quirk_terms below).
+// taps are split into hi + lo halves (22 significant bits); the intermediate V (24-bit fixed point in memory) is split
+// into hi + lo halves when the column pass decodes it; products are exact in the f32 accumulators of
+// v_mfma_f32_32x32x16_f16.  The Nyquist-slot quirk of pffft_() (Source.cpp:420-425) is a rank-one term per line, made of
+// exact integer alternating sums of the image that the row kernel leaves behind as partial sums (notes further down).
 //
-//   mx_rowpass_u8   u8 BGR image -> V[row][3 x + c] f32 (row pitch = a multiple of 32 floats)
+//   mx_rowpass_u8   u8 BGR image -> V (24-bit fixed point, [strip][8 rows][lane][24 bytes], see MxV24x8)
 //       unit = 32 rows x 128 pixels: reflect-101 + deinterleave + u8 -> f16 into LDS, A = data (32 rows x 16 window
-//       positions), B = Toeplitz fragment (registers), D = 32 rows x 32 outputs; re-interleaved through LDS, float4 stores
+//       positions), B = Toeplitz fragment (registers), D = 32 rows x 32 outputs; re-interleaved through LDS, packed to
+//       24 bits and stored as 24-byte operand fragments
 //   mx_colpass_u8   V -> u8 BGR image
-//       a wave owns 32 adjacent floats of V's rows (one 128-byte line per row) and walks down the image: each 16-row
-//       block is loaded ONCE (coalesced, straight into the B operand: lane = column, 8 consecutive rows), split into
-//       hi + lo halves, and multiplied into the (NKB + 1) / 2 output tiles whose windows contain it (A = Toeplitz
-//       fragment of the block's offset in that tile's window).  No LDS, no barrier; channels never need separating
-//       because the convolution runs along rows of V and every interleaved column is independent.
+//       a wave owns 32 adjacent values of V's rows and walks down the image: each 16-row block is loaded ONCE (two loads:
+//       the lane's 8 consecutive rows are 24 contiguous bytes), decoded, split into hi + lo halves, and multiplied into
+//       the (NKB + 1) / 2 output tiles whose windows contain it (A = Toeplitz fragment of the block's offset in that
+//       tile's window).  No LDS, no barrier; channels never need separating because the convolution runs along rows of
+//       V and every interleaved column is independent.
+//   mx_quirk_rows, mx_quirk_cols   the quirk's two term vectors from the row kernel's partial sums
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -45,9 +47,6 @@ constexpr float kMxUnscale = 1.f / 16384.f;   // 2^-kMxScaleLog2 (host_math.hpp)
 // 12 of every 15 B/px that are V.  Layout: [frame][strip of 32 values of a V row][group of 8 rows][lane 0..31][24 bytes]
 // -- the 24 bytes are the lane's 8 consecutive rows, exactly its B-operand fragment of the column pass: two loads per
 // 16-row block instead of eight, 768 contiguous bytes per (strip, row group).
-#ifndef MX_V24
-#define MX_V24 1
-#endif
 constexpr float kMxV24Scale = 65536.f, kMxV24Offset = 0.f;
 struct __attribute__((packed, aligned(8))) MxV24x8 { uint32_t d[6]; };
 
@@ -328,7 +327,6 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
             }
         }
         __syncthreads();
-#if MX_V24
         {   // 12 strips x 4 row groups x 32 lanes = 1536 fragments of 24 bytes, six per thread; a wave stores 2 x 768 contiguous bytes
             unsigned char* vbase = reinterpret_cast<unsigned char*>(V) + static_cast<size_t>(f) * (g.vpitch / 32) * (g.vrows / 8) * 768;
 #pragma unroll
@@ -343,17 +341,6 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
                 }
             }
         }
-#else
-        {   // thread t stores row t >> 3: twelve float4, 128 bytes apart
-            const int row = tid >> 3, q0 = tid & 7;
-            float* vrow = V + (static_cast<size_t>(f) * g.vrows + r0 + row) * g.vpitch + 3 * x0 + 4 * q0;
-            const float* srow = stage + row * kMxStagePitch + 4 * q0;
-            const int room = g.vpitch - 3 * x0 - 4 * q0;               // floats left in the row of V
-#pragma unroll
-            for (int j = 0; j < 12; ++j)
-                if (32 * j < room) *reinterpret_cast<float4*>(vrow + 32 * j) = *reinterpret_cast<const float4*>(srow + 32 * j);
-        }
-#endif
         __syncthreads();
     }
 }
@@ -397,23 +384,11 @@ __global__ __launch_bounds__(256, MX_COL_WAVES(NKB)) void mx_colpass_u8(const fl
     const int e = 32 * s + n;
     const bool valid = e < 3 * g.cols;
     const uint32_t rowbytes = 3u * g.cols;
-#if !MX_V24
-    const uint32_t vrowbytes = 4u * g.vpitch;
-#endif
-#if MX_V24
     const uint32_t stripbytes = static_cast<uint32_t>(g.vrows / 8) * 768u;
     const unsigned char* strip = reinterpret_cast<const unsigned char*>(V) + (static_cast<size_t>(f) * nstrips + s) * stripbytes;   // uniform
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(strip), 0, stripbytes, kMxRsrcWord3);
-#else
-    const float* strip = V + static_cast<size_t>(f) * g.vrows * g.vpitch + 32 * s;                // uniform
-    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(strip), 0, g.vrows * vrowbytes - 128u * s, kMxRsrcWord3);
-#endif
     uint8_t* ostrip = dst + static_cast<size_t>(f) * g.rows * rowbytes + 32 * s;                   // uniform
-#if MX_V24
     const uint32_t lane_in = 24u * n + 768u * h;                                                   // byte offset inside a block (two row groups)
-#else
-    const uint32_t lane_in = 4u * n + 8u * h * vrowbytes;                                          // byte offset inside a block
-#endif
     const uint32_t lane_out = valid ? n + 4u * h * rowbytes : 0xfffffff0u;                         // invalid column: out of bounds
 
     mx_half8 th[NKB], tl[NKB];
@@ -436,7 +411,6 @@ __global__ __launch_bounds__(256, MX_COL_WAVES(NKB)) void mx_colpass_u8(const fl
     }
 
     const int nblocks = g.vrows / 16;
-#if MX_V24
     constexpr int QW = 6;
     auto load_block = [&](int jb, uint32_t (&d)[6]) {
         // blocks past the end are never part of an emitted tile: read the last one again instead
@@ -456,16 +430,6 @@ __global__ __launch_bounds__(256, MX_COL_WAVES(NKB)) void mx_colpass_u8(const fl
     };
     uint32_t queue[PD][QW];
     float qqueue[QUIRK ? PD : 1][8];
-#else
-    constexpr int QW = 8;
-    auto load_block = [&](int jb, float (&v)[8]) {
-        // blocks past the end are never part of an emitted tile: read the last one again instead
-        const uint32_t row0 = 16u * min(jb, nblocks - 1) * vrowbytes;                               // uniform
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, lane_in, row0 + q * vrowbytes, 0));
-    };
-    float queue[PD][QW];
-#endif
     const int ntiles = (g.rows + 31) / 32;
     const int tile0 = seg * tps, tile1 = min(tile0 + tps, ntiles);             // this segment's output tiles
     // the output resource covers exactly the segment's rows of the strip: rows of other segments (the incomplete tiles of the
@@ -497,16 +461,11 @@ __global__ __launch_bounds__(256, MX_COL_WAVES(NKB)) void mx_colpass_u8(const fl
                 typedef uint32_t u4 __attribute__((ext_vector_type(4)));
                 u4 w1, w2;
                 float vv[8];
-#if MX_V24
                 mx_v24_unpack(queue[slotq], vv);
                 if (QUIRK) {
 #pragma unroll
                     for (int k = 0; k < 8; ++k) vv[k] = __builtin_fmaf(qqueue[slotq][k], sgn_x, vv[k]);
                 }
-#else
-#pragma unroll
-                for (int k = 0; k < 8; ++k) vv[k] = queue[slotq][k];
-#endif
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const f2 v = { vv[2 * k], vv[2 * k + 1] };
@@ -525,10 +484,8 @@ __global__ __launch_bounds__(256, MX_COL_WAVES(NKB)) void mx_colpass_u8(const fl
                     const int d = 2 * a + b, slot = (q - a + 2 * NACC) % NACC;
                     mx_float16 c = d == 0 ? zero : acc[slot];
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v1, c, 0, 0, 0);
-#ifndef MX_COL_ONE_MFMA
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[d], v1, c, 0, 0, 0);
                     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v2, c, 0, 0, 0);
-#endif
                     acc[slot] = c;
                 }
                 if ((NKB - 1 - b) % 2 == 0) {            // the tile whose last window block this was
@@ -541,9 +498,6 @@ __global__ __launch_bounds__(256, MX_COL_WAVES(NKB)) void mx_colpass_u8(const fl
 #pragma unroll
                         for (int reg = 0; reg < 16; ++reg) {
                             const float v = __builtin_fmaf(acc[slot][reg], kMxUnscale, (reg & 1) ? cneg : cpos);
-#ifdef MX_COL_NO_STORE
-                            if (v == 12345.678f)
-#endif
                             __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(static_cast<int>(v)), rout, lane_out,
                                                                  orow0 + static_cast<uint32_t>((reg & 3) + 8 * (reg >> 2)) * rowbytes, 0);
                         }
