@@ -34,7 +34,6 @@ namespace blur_amd {
 
 typedef _Float16 mx_half8 __attribute__((ext_vector_type(8)));
 typedef float mx_float16 __attribute__((ext_vector_type(16)));
-typedef __fp16 mx_fp16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kMxRowChunk = 128;        // pixels per row-pass unit
 constexpr int kMxStagePitch = 392;      // floats per staged row (384 + 8: the two half-waves land in disjoint banks)
