@@ -11,7 +11,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("$OUT/*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "mx_" not in k: continue
+        if "mx_" not in k and "box" not in k: continue
         k = k.split("(")[0][-60:]
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, d in acc.items():
