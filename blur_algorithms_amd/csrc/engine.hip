@@ -987,8 +987,8 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
         // anything of the kernel array outside +-pad would be lost here: the Toeplitz band is 2 pad + 1 wide
         for (int i = pad + 1; i < n - pad; ++i)
             if (karr[ax][i] != 0.f) return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: kernel wider than 2 pad + 1");
-        // the 24-bit intermediate of the kernels (mx_kernels.hpp) covers [-256, 512): non-negative taps with sum <= 1 keep the
-        // row pass inside 0..255, and a quirk gain m[0] - m[N/2] <= 1/N keeps its term inside +-255
+        // the 24-bit intermediate of the kernels (mx_kernels.hpp) covers [0, 256): non-negative taps with sum <= 1 keep the
+        // row pass inside 0..255.13 (the quirk's terms are added in f32 after it is decoded: no bound on them)
         {
             double sum = 0;
             bool neg = false;
@@ -1011,8 +1011,6 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
         (ax ? t.frags_col : t.frags_row) = dfr;
         (ax ? t.taps_col : t.taps_row) = dt;
         (ax ? t.dc : t.dr) = m0 - mh;
-        if (std::fabs(static_cast<double>(m0 - mh)) * n > 1.003)   // (a truncated Gaussian reaches 1.0015: its alternating sum is slightly negative)
-            return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: Nyquist gain of the kernel out of range");
     }
     *out = &(ctx->mx_tables[key] = t);
     return BLUR_OK;

@@ -43,8 +43,9 @@ def test_matrix_engine_batch_and_constant(ctx):
 
 
 # one sigma per instantiated window size (NKB = 3, 5, ..., 23: pad 0..168), odd image sizes, both quirk settings;
-# rows, cols > pad.  sigma 2.5 -> pad 7 (NKB 3) ... sigma 50 -> pad 166 (NKB 23)
-EVERY_WINDOW = [(2.5, 3), (7.5, 5), (12.5, 7), (17.0, 9), (22.0, 11), (26.5, 13), (31.5, 15), (36.5, 17), (41.0, 19), (46.0, 21), (50.0, 23)]
+# rows, cols > pad.  sigma 2.5 -> pad 7 (NKB 3) ... sigma 50 -> pad 166 (NKB 23); sigma 2.0 is the truncated Gaussian whose
+# alternating sum is most negative (Nyquist gain 1.0037)
+EVERY_WINDOW = [(2.0, 3), (2.5, 3), (7.5, 5), (12.5, 7), (17.0, 9), (22.0, 11), (26.5, 13), (31.5, 15), (36.5, 17), (41.0, 19), (46.0, 21), (50.0, 23)]
 
 
 @pytest.mark.parametrize("sigma,nkb", EVERY_WINDOW)
