@@ -166,7 +166,6 @@ __device__ __forceinline__ void mx_row_issue(MxRowRaw<NKB>& raw, const uint8_t* 
     }
 }
 
-// deinterleave + u8 -> binary16 + write to the LDS window [c][row][PW]
 // weight of element i of a line of `len` elements in the alternating sum of its reflect-101 padded line (see the quirk notes below)
 __device__ __forceinline__ int mx_alt_weight(int i, int len, int pad)
 {
@@ -356,11 +355,13 @@ constexpr uint32_t kMxRsrcWord3 = 0x00020000u;   // raw buffer, 32-bit data form
 // QUIRK: V[re][e] += qrow[f][c][re] * (-1)^x when a block is decoded (the row pass's Nyquist-slot term; qrow is indexed by the
 // row of V, mirrored rows included), and out += qcol[f][e] * (-1)^r (the column pass's term); e = 3 x + c.  The qrow loads
 // ride with the block's data loads -- same place in the in-order vmcnt queue, consumed together
-// All global accesses are buffer instructions: resource = this wave's strip of this frame, vector offset = the lane's
-// constant byte offset, scalar offset = the row -- no vector arithmetic per access, and a store whose offset lies past
-// the image (rows of the last partial tile, columns past 3 cols) is dropped by the bounds check of the resource.
-// two waves per SIMD while 2 NKB fragments + NACC accumulator tiles fit 256 registers without spills (NKB = 11: the metric), then with 2 blocks in flight per
-// wave; one wave per SIMD and 4 blocks otherwise.  Measured for NKB = 11 with the quirk's terms: 30.7 against 32.1 us per frame.
+// All global accesses are buffer instructions: resource = this wave's strip of this frame (output: this segment's rows of it),
+// vector offset = the lane's constant byte offset, scalar offset = the block or row -- no vector arithmetic per access, and a
+// store whose offset lies outside the resource (rows of another segment or past the image, columns past 3 cols) is dropped by
+// its bounds check.
+// Two waves per SIMD while 2 NKB fragments + NACC accumulator tiles fit 256 registers without spills (NKB = 11: the metric), then
+// with 2 blocks in flight per wave; one wave per SIMD and 4 blocks otherwise.  Measured for NKB = 11 with the quirk's terms: 30.7
+// against 32.1 us per frame.
 #ifndef MX_COL_WAVES
 #define MX_COL_WAVES(NKB_) ((NKB_) == 11 ? 2 : 1)
 #endif
@@ -514,13 +515,13 @@ __global__ __launch_bounds__(256, MX_COL_WAVES(NKB)) void mx_colpass_u8(const fl
 // i.e. one alternating sum per line.  With reflect-101 borders that sum is a weighted sum of the image line itself:
 // pixel i sits at p = i + pad and its mirror images (1 <= i <= pad on the left, len-1-pad <= i <= len-2 on the right)
 // all land on positions of the same parity, so weight(i) = (-1)^(i+pad) * (1 + [left mirror] + [right mirror]).
-// Both passes together (row pass R, then column pass on R's output):
-//     out[r][x] = conv2(img)[r][x] + dr (-1)^(x+pad) G(r) + dc (-1)^(r+pad) Scol(x)
-//     G(r)    = sum_t taps[t] Srow(refl(r + t)),            Srow(r) = sum_x wx(x) img[r][x]           (integers)
-//     Scol(x) = sum_t taps[t] A(refl(x + t)) + dr (-1)^(x+pad) Z,   A(x) = sum_r wy(r) img[r][x],  Z = sum_x wx(x) A(x)
-// mx_altsums reads the image once for Srow and A (exact integers: the result does not depend on the order of the
-// additions); mx_quirk_terms turns them into the two float vectors the column kernel adds.
-
+// Both passes together (wx, wy: the weights along a row and along a column):
+//     V'[r][x]  = V[r][x] + dr (-1)^(x+pad) Srow(r),          Srow(r) = sum_x wx(x) img[r][x]                    (integers)
+//     out[r][x] = colconv(V')[r][x] + dc (-1)^(r+pad) Scol(x),  Scol(x) = sum_r wy(r) V'[r][x]
+//                                                                     = sum_r wy(r) V[r][x] + dr (-1)^(x+pad) Z,  Z = sum_r wy(r) Srow(r)
+// The row kernel leaves the partial sums behind (spart: Srow per 128-pixel chunk; vpart: the wy-weighted column sums of V per
+// 32-row block); mx_quirk_rows and mx_quirk_cols add them up in a fixed order and produce the two float vectors the column
+// kernel adds: qrow (per row of V, when a block is decoded) and qcol (per column, when a tile leaves).
 #ifdef BLUR_MX_QUIRK_KERNELS   // engine.hip only: plain (non-template) kernels must live in one translation unit
 // Rows: Srow[r][c] = sum over the chunks of spart (integers); qrow[f][c][re] = dr (-1)^pad Srow[refl(re - PADA)][c] for every
 // row re of V; zpart[f][block][c] = the block's part of Z_c = sum_r wy(r) Srow[r][c].  grid: (ceil(vrows / 256), frames)
