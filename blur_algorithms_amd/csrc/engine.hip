@@ -1041,18 +1041,33 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     // an error;  1 / 2 / 5 the FFT kernels (1 never wave-resident, 2 wave-resident wherever it fits, 5 the measured FFT policy below).
     const int choice = opts ? opts->reserved[3] : 0;
     // (allow_wr = false: the caller wants the rows-first float planes themselves, blur_rowpass_u8c3_dev)
-    // Small frames: the matrix-core path is five launches (three for the quirk's pre-pass) against two, and one small frame
-    // does not fill the chip either way, so below 1 MP the library's own choice stays with the FFT kernels WHEN they have a
-    // compile-time family for both passes (the run-time-planned kernels are 3-4 times slower: then the matrix cores win
-    // again).  The choice depends on the frame only, never on the number of frames: a frame blurred alone and the same
-    // frame inside a batch give the same bytes.  (One frame per call, us: 1080p sigma 20 92 matrix / 72 FFT, 4K 147 / 150;
-    // eight frames per call: 1080p 24 / 37 per frame, 4K 74 / 104.)
+    // Where the library's own choice (reserved[3] = 0) stays with the FFT kernels although a matrix-core kernel exists -- only
+    // when the FFT engine has a compile-time family that its own policy below would pick (the run-time-planned kernels are
+    // 3-4 times slower: then the matrix cores win regardless):
+    //  * small frames (< 1 MP): the matrix-core path is four launches against two, and one small frame does not fill the chip
+    //    either way (one frame per call, us: 1080p sigma 20 78 matrix / 72 FFT; eight per call: 23 / 36 per frame);
+    //  * wide kernels (19 window blocks and more, pad > 136): the row kernel's window is then 3-4 times its 128 output pixels and
+    //    its fragments leave one workgroup per CU (4K, 8 frames per call, GP/s matrix / FFT: sigma 36 80 / 76, sigma 40 72 / 73,
+    //    sigma 44 66 / 72, sigma 50 63 / 72).
+    // The choice depends on the frame and the kernel only, never on the number of frames: a frame blurred alone and the same
+    // frame inside a batch give the same bytes.
     bool small_fft = false;
-    if (choice == 0 && static_cast<long long>(rows) * cols < 1000000ll) {
-        const WrEntry* wc = find_wr_entry(rows + 2 * p.sz.pad, true);
-        const WrEntry* wr = find_wr_entry(cols + 2 * p.sz.pad, false);
-        small_fft = (wc && wr && wc->col_lds(rows) <= kLdsLimit && wr->row_lds(cols) <= kLdsLimit) ||
-                    (find_fast_entry(p.sz.n_col, true) && find_fast_entry(p.sz.n_row, false));
+    if (choice == 0) {
+        const MxEntry* me0 = find_mx_entry(p.sz.pad);
+        // (wide: measured on 4K frames only; the 1.5-3.8 MP images of the reference's sweep with sigma 39-49 run 1.0-1.5 times
+        // FASTER on the matrix cores than on the wave-resident FFT kernels, so the rule is limited to large frames)
+        const bool small = static_cast<long long>(rows) * cols < 1000000ll, wide = me0 && me0->nkb >= 19 && static_cast<long long>(rows) * cols >= 6000000ll;
+        if (small || wide) {
+            const WrEntry* wc = find_wr_entry(rows + 2 * p.sz.pad, true);
+            const WrEntry* wr = find_wr_entry(cols + 2 * p.sz.pad, false);
+            const bool old_both = find_fast_entry(p.sz.n_col, true) && find_fast_entry(p.sz.n_row, false);
+            bool wr_pays = false;
+            if (wc && wr && wc->col_lds(rows) <= kLdsLimit && wr->row_lds(cols) <= kLdsLimit) {
+                const int need_c = rows + 2 * p.sz.pad, need_r = cols + 2 * p.sz.pad, nc = wc->r0 * kWrS, nr = wr->r0 * kWrS;
+                wr_pays = old_both ? (wc->r0 >= 8 && wr->r0 >= 12 && 4 * need_c >= 3 * nc && 4 * need_r >= 3 * nr) : (2 * need_c >= nc && 2 * need_r >= nr);
+            }
+            small_fft = wr_pays || old_both;
+        }
     }
     if (allow_fast && allow_wr && !small_fft && (choice == 0 || choice == 3)) {
         const MxEntry* me = find_mx_entry(p.sz.pad);

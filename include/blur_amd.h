@@ -53,8 +53,10 @@ typedef struct blur_opts {
        reserved[2] = 1: keep the float intermediate in row-major planes even when both passes are
        specialised (default: strips of 8 columns stored contiguously);
        reserved[3]: which kernels run the u8c3 blur.  0 = the library's choice: the matrix-core kernels
-       (mx_kernels.hpp: both passes as banded Toeplitz products on the f16 MFMA units) wherever one is
-       instantiated for the kernel's half width (pad <= 168), the FFT kernels otherwise;
+       (mx_kernels.hpp: both passes as banded Toeplitz products on the f16 MFMA units) where one is
+       instantiated for the kernel's half width (pad <= 168) -- except small frames and very wide kernels on
+       large frames when the FFT engine has a compile-time family for them (engine.hip: prepare()) -- and the
+       FFT kernels otherwise;
        3 = the matrix-core kernels (BLUR_ERR_UNSUPPORTED if none fits);
        5 = the FFT kernels with their own measured choice of family, 1 = FFT, never the wave-resident family,
        2 = FFT, wave-resident (transform length 256 * R0, columns first) wherever the image fits (tests, A/B timing) */

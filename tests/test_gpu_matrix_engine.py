@@ -90,6 +90,13 @@ def test_the_librarys_choice_of_engine(ctx):
     assert fam() == 2
     ctx.pffft_(batch[0], 20.0)                                    # one frame of the batch: the same engine as the batch
     assert fam() == 4
+    uhd = torch.zeros((2, 2160, 3840, 3), dtype=torch.uint8, device="cuda")
+    ctx.pffft_(uhd, 20.0)
+    assert fam() == 4
+    ctx.pffft_(uhd, 50.0)                                         # 4K, 327 taps: the specialised FFT kernels (4320 / 2560) are faster
+    assert fam() == 1
+    ctx.pffft_(uhd, 50.0, engine="matrix")
+    assert fam() == 4
     ctx.pffft_(small.clone(), 20.0, engine="matrix")
     assert fam() == 4
     ctx.separable(big, np.array([0.25, 0.5, 0.25], np.float32))
