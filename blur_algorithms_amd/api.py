@@ -136,7 +136,7 @@ class BlurContext:
         # kernels otherwise); "matrix" = Toeplitz products on the f16 matrix cores (mx_kernels.hpp); "fft" = the FFT kernels
         # with their own measured choice of family; "wave-resident" / "rows-first" = one FFT family
         if engine is not None:
-            o.reserved[3] = {"matrix": 3, "wave-resident": 2, "rows-first": 1, "fft": 5}[engine]
+            o.reserved[3] = {"matrix": 3, "wave-resident": 2, "rows-first": 1, "fft": 5, "fused": 6}[engine]
         return o
 
     def use_torch_stream(self):
@@ -148,6 +148,14 @@ class BlurContext:
 
     def synchronize(self):
         self._check(self._lib.blur_ctx_synchronize(self._h))
+
+    def last_family(self):
+        """kernels the last u8c3 blur ran on: 0 run-time plans, 1 rows-first, 2 wave-resident, 3 whole-image 2D, 4 matrix-core
+        (two kernels), 6 fused matrix-core (debug query, not declared in the public header)"""
+        fn = self._lib.blur_debug_last_family
+        fn.argtypes = [C.c_void_p]
+        fn.restype = C.c_int
+        return int(fn(self._h))
 
     def timing_enable(self, on=True):
         self._check(self._lib.blur_ctx_timing_enable(self._h, 1 if on else 0))

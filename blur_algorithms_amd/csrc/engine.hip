@@ -31,6 +31,7 @@
 #include "host_math.hpp"
 #define BLUR_MX_QUIRK_KERNELS
 #include "mx_registry.hpp"
+#include "fx_registry.hpp"
 #include "wr_registry.hpp"
 
 using namespace blur_amd;
@@ -616,6 +617,14 @@ struct MxTables {
     float* taps_row = nullptr;   // 2 pad + 1 floats, centre at pad
     float* taps_col = nullptr;
     float dr = 0.f, dc = 0.f;    // m[0] - m[N/2] of the reference's row / column transform length (the quirk's gain)
+    std::vector<float> host_taps;   // 2 pad + 1 floats (the same along both axes)
+    int pad = 0;
+};
+
+// fused kernel (fx_kernels.hpp): fragment sets with the row borders folded in, per (kernel, image width)
+struct FxTables {
+    void* frags = nullptr;       // [sets][2][nkb][64][8] binary16 (host_math.hpp: fx_fragment_sets)
+    uint16_t* tilemap = nullptr; // device: set of each tile column
 };
 
 struct blur_ctx {
@@ -634,6 +643,7 @@ struct blur_ctx {
     std::map<std::tuple<int, int, int, int, uint64_t>, float*> wr_spectra;   // (n, n_ref, ksize | -1, quirk, sigma bits | hash)
     // matrix-core engine (mx_kernels.hpp): Toeplitz fragments + taps per kernel, integer sums and float terms of the quirk
     std::map<std::tuple<int, int, int, uint64_t>, MxTables> mx_tables;   // (ksize | -1, n_row, n_col, sigma bits | hash); one nkb per pad
+    std::map<std::tuple<const void*, int, int>, FxTables> fx_tables;         // (the kernel's MxTables entry, cols, nkb)
     int* mx_sums = nullptr;
     size_t mx_sums_bytes = 0;
     float* mx_terms = nullptr;
@@ -888,6 +898,8 @@ struct Prepared {
     float *wr_m_col = nullptr, *wr_m_row = nullptr;
     // matrix-core kernels (both passes)
     const MxEntry* mx = nullptr;
+    const FxEntry* fx = nullptr;      // fused kernel (fx_kernels.hpp); taps and quirk gains shared with the two-kernel matrix engine
+    const FxTables* fxt = nullptr;
     const MxTables* mxt = nullptr;
     int mx_vpitch = 0;
     bool mx_quirk = false;
@@ -1011,8 +1023,27 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
         (ax ? t.frags_col : t.frags_row) = dfr;
         (ax ? t.taps_col : t.taps_row) = dt;
         (ax ? t.dc : t.dr) = m0 - mh;
+        if (ax == 0) { t.host_taps = taps; t.pad = pad; }
     }
     *out = &(ctx->mx_tables[key] = t);
+    return BLUR_OK;
+}
+
+static int fx_get_tables(blur_ctx* ctx, const MxTables* mt, int nkb, int cols, const FxTables** out)
+{
+    const auto key = std::make_tuple(static_cast<const void*>(mt), cols, nkb);
+    auto it = ctx->fx_tables.find(key);
+    if (it != ctx->fx_tables.end()) { *out = &it->second; return BLUR_OK; }
+    std::vector<uint16_t> map((cols + 31) / 32);
+    const int sets = fx_fragment_sets(mt->host_taps.data(), mt->pad, nkb, cols, map.data(), nullptr);
+    std::vector<uint16_t> fr(static_cast<size_t>(sets) * 2 * nkb * 512);
+    fx_fragment_sets(mt->host_taps.data(), mt->pad, nkb, cols, map.data(), fr.data());
+    FxTables t;
+    HIP_TRY(ctx, hipMalloc(&t.frags, fr.size() * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMemcpy(t.frags, fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t.tilemap), map.size() * sizeof(uint16_t)));
+    HIP_TRY(ctx, hipMemcpy(t.tilemap, map.data(), map.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+    *out = &(ctx->fx_tables[key] = t);
     return BLUR_OK;
 }
 
@@ -1068,6 +1099,18 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
             }
             small_fft = wr_pays || old_both;
         }
+    }
+    if (allow_fast && allow_wr && choice == 6) {
+        const FxEntry* fe = find_fx_entry(p.sz.pad);
+        if (!fe) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: no kernel instantiated for this pad");
+        if (static_cast<long long>(rows) * cols * 3 >= (1ll << 32)) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: frame too large for 32-bit offsets");
+        if ((cols & 3) != 0) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: the image width must be a multiple of 4");
+        if (int rc = mx_get_tables(ctx, fe->nkb, sigma, p.sz, ck, &p.mxt)) return rc;
+        if (int rc = fx_get_tables(ctx, p.mxt, fe->nkb, cols, &p.fxt)) return rc;
+        p.fx = fe;
+        p.mx_quirk = quirk;
+        p.frame_elems = 0;
+        return BLUR_OK;
     }
     if (allow_fast && allow_wr && !small_fft && (choice == 0 || choice == 3)) {
         const MxEntry* me = find_mx_entry(p.sz.pad);
@@ -1352,6 +1395,10 @@ int blur_ctx_destroy(blur_ctx* ctx)
         (void)hipFree(kv.second.frags_row); (void)hipFree(kv.second.frags_col);
         (void)hipFree(kv.second.taps_row); (void)hipFree(kv.second.taps_col);
     }
+    for (auto& kv : ctx->fx_tables) {
+        if (kv.second.frags) (void)hipFree(kv.second.frags);
+        if (kv.second.tilemap) (void)hipFree(kv.second.tilemap);
+    }
     if (ctx->mx_sums) (void)hipFree(ctx->mx_sums);
     if (ctx->mx_terms) (void)hipFree(ctx->mx_terms);
     if (ctx->work) (void)hipFree(reinterpret_cast<char*>(ctx->work) - kWorkGuard);
@@ -1474,6 +1521,28 @@ static int run_mx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     return BLUR_OK;
 }
 
+// both passes in one kernel on the matrix cores (fx_kernels.hpp): no intermediate in memory
+static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes, int rows, int cols, const Prepared& p)
+{
+    if (p.mx_quirk) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: quirk terms not wired yet");
+    const size_t px = static_cast<size_t>(rows) * cols;
+    // in place (the reference's own calling convention, Source.cpp:429,567): a strip reads its neighbours' columns and the rows
+    // below while they are being written, so the frames are read from a copy in the workspace
+    const uint8_t* lo = d_src < d_dst ? d_src : d_dst;
+    const uint8_t* hi = d_src < d_dst ? d_dst : d_src;
+    if (static_cast<size_t>(hi - lo) < px * 3 * nframes) {
+        if (int rc = ensure_work(ctx, px * 3 * nframes)) return rc;
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->work, d_src, px * 3 * nframes, hipMemcpyDeviceToDevice, ctx->stream));
+        d_src = reinterpret_cast<const uint8_t*>(ctx->work);
+    }
+    FxGeom g{ rows, cols, p.sz.pad, nframes, 0, (rows + 31) / 32 };
+    g.aligned = ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 3) == 0) ? 1 : 0;
+    if (!g.aligned) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: frame pointers must be 4-byte aligned");
+    { TimedLaunch t(ctx, 0, nframes);
+      HIP_TRY(ctx, p.fx->blur_u8(ctx->stream, d_src, d_dst, p.fxt->frags, p.fxt->tilemap, g, ctx->num_cus, nullptr, nullptr, 0)); }
+    return BLUR_OK;
+}
+
 static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes,
                                 int rows, int cols, double sigma, const blur_opts* opts, const CustomKernel* ck)
 {
@@ -1486,6 +1555,11 @@ static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_
     // 8: 0.140 -- the kernels are latency bound, not HBM bound, so filling every CU evenly and amortising
     // the per-workgroup table loads is worth more than keeping the float intermediate inside the 256 MiB
     // Infinity Cache.  The workspace is capped at 1 GiB.
+    if (p.fx) {
+        if (nframes == 0) return BLUR_OK;
+        ctx->last_family = 6;
+        return run_fx_u8c3(ctx, d_src, d_dst, nframes, rows, cols, p);
+    }
     int chunk = opts && opts->reserved[1] > 0 ? opts->reserved[1] : static_cast<int>((1024u << 20) / (p.frame_elems * sizeof(float)));
     if (chunk < 1) chunk = 1;
     if (chunk > nframes) chunk = nframes;

@@ -1,0 +1,43 @@
+"""tools/fx_dev.py -- the fused matrix-core kernel against the two-kernel matrix engine (GPU box): bytes and time.
+usage: python tools/fx_dev.py [--quirk] [--no-check] [frames]"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy as np
+import torch
+
+import blur_algorithms_amd as B
+
+quirk = "--quirk" in sys.argv
+check = "--no-check" not in sys.argv
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+nf = int(args[0]) if args else 8
+ctx = B.BlurContext(0)
+g = torch.Generator(device="cuda").manual_seed(1)
+if check:
+    for rows, cols, sigma, n in ((200, 300, 20.0, 1), (256, 384, 20.0, 2), (332, 516, 18.5, 1), (70, 68, 20.0, 1), (66, 132, 20.0, 3), (1080, 1920, 20.0, 1), (2160, 3840, 20.0, 2), (90, 4004, 19.0, 1)):
+        fr = torch.randint(0, 256, (n, rows, cols, 3), dtype=torch.uint8, device="cuda", generator=g)
+        a = ctx.pffft_(fr, sigma, out=torch.empty_like(fr), nyquist_quirk=quirk, engine="matrix")
+        b = ctx.pffft_(fr, sigma, out=torch.empty_like(fr), nyquist_quirk=quirk, engine="fused")
+        d = (a.int() - b.int()).abs()
+        bad = (d > 1).nonzero()
+        print("%4d x %4d sigma %.1f n %d: max diff %d, differing %.2e, family %d%s" % (
+            rows, cols, sigma, n, int(d.max()), float((d != 0).float().mean()), ctx.last_family(),
+            "" if bad.numel() == 0 else "  first bad at %s (of %d)" % (bad[0].tolist(), bad.shape[0])), flush=True)
+rows, cols, sigma = 2160, 3840, 20.0
+frames = torch.randint(0, 256, (nf, rows, cols, 3), dtype=torch.uint8, device="cuda", generator=g)
+out = torch.empty_like(frames)
+for eng in ("fused", "matrix", "fused"):
+    for _ in range(10):
+        ctx.pffft_(frames, sigma, out=out, nyquist_quirk=quirk, engine=eng)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 20
+    for _ in range(n):
+        ctx.pffft_(frames, sigma, out=out, nyquist_quirk=quirk, engine=eng)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print("engine %-8s quirk %d: %.3f ms/step  %.1f us/frame  %.1f GP/s" % (eng, quirk, dt * 1e3, dt / nf * 1e6, nf * rows * cols / dt / 1e9), flush=True)
