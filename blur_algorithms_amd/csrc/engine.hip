@@ -31,6 +31,7 @@
 #include "host_math.hpp"
 #define BLUR_MX_QUIRK_KERNELS
 #include "mx_registry.hpp"
+#define BLUR_FX_QUIRK_KERNELS
 #include "fx_registry.hpp"
 #include "wr_registry.hpp"
 
@@ -617,14 +618,6 @@ struct MxTables {
     float* taps_row = nullptr;   // 2 pad + 1 floats, centre at pad
     float* taps_col = nullptr;
     float dr = 0.f, dc = 0.f;    // m[0] - m[N/2] of the reference's row / column transform length (the quirk's gain)
-    std::vector<float> host_taps;   // 2 pad + 1 floats (the same along both axes)
-    int pad = 0;
-};
-
-// fused kernel (fx_kernels.hpp): fragment sets with the row borders folded in, per (kernel, image width)
-struct FxTables {
-    void* frags = nullptr;       // [sets][2][nkb][64][8] binary16 (host_math.hpp: fx_fragment_sets)
-    uint16_t* tilemap = nullptr; // device: set of each tile column
 };
 
 struct blur_ctx {
@@ -642,8 +635,7 @@ struct blur_ctx {
     std::map<int, float2*> wr_tw0;
     std::map<std::tuple<int, int, int, int, uint64_t>, float*> wr_spectra;   // (n, n_ref, ksize | -1, quirk, sigma bits | hash)
     // matrix-core engine (mx_kernels.hpp): Toeplitz fragments + taps per kernel, integer sums and float terms of the quirk
-    std::map<std::tuple<int, int, int, uint64_t>, MxTables> mx_tables;   // (ksize | -1, n_row, n_col, sigma bits | hash); one nkb per pad
-    std::map<std::tuple<const void*, int, int>, FxTables> fx_tables;         // (the kernel's MxTables entry, cols, nkb)
+    std::map<std::tuple<int, int, int, int, int, uint64_t>, MxTables> mx_tables;   // (ksize | -1, pad, nkb, n_row, n_col, sigma bits | hash)
     int* mx_sums = nullptr;
     size_t mx_sums_bytes = 0;
     float* mx_terms = nullptr;
@@ -899,7 +891,6 @@ struct Prepared {
     // matrix-core kernels (both passes)
     const MxEntry* mx = nullptr;
     const FxEntry* fx = nullptr;      // fused kernel (fx_kernels.hpp); taps and quirk gains shared with the two-kernel matrix engine
-    const FxTables* fxt = nullptr;
     const MxTables* mxt = nullptr;
     int mx_vpitch = 0;
     bool mx_quirk = false;
@@ -988,7 +979,9 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
     }
     if (ck) { kkey = -1; tag = fnv1a(karr[0].data(), nn[0] * sizeof(float)) ^ (fnv1a(karr[1].data(), nn[1] * sizeof(float)) * 3); }
     else { kkey = sz.kSize; std::memcpy(&tag, &sigma, sizeof tag); }
-    const auto key = std::make_tuple(kkey, nn[0], nn[1], tag);
+    // (pad and nkb are part of the key: the same taps with another pad, or the two-kernel and the fused engine with different
+    // window sizes for one pad, have different fragment tables)
+    const auto key = std::make_tuple(kkey, pad, nkb, nn[0], nn[1], tag);
     auto it = ctx->mx_tables.find(key);
     if (it != ctx->mx_tables.end()) { *out = &it->second; return BLUR_OK; }
     MxTables t;
@@ -1023,27 +1016,8 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
         (ax ? t.frags_col : t.frags_row) = dfr;
         (ax ? t.taps_col : t.taps_row) = dt;
         (ax ? t.dc : t.dr) = m0 - mh;
-        if (ax == 0) { t.host_taps = taps; t.pad = pad; }
     }
     *out = &(ctx->mx_tables[key] = t);
-    return BLUR_OK;
-}
-
-static int fx_get_tables(blur_ctx* ctx, const MxTables* mt, int nkb, int cols, const FxTables** out)
-{
-    const auto key = std::make_tuple(static_cast<const void*>(mt), cols, nkb);
-    auto it = ctx->fx_tables.find(key);
-    if (it != ctx->fx_tables.end()) { *out = &it->second; return BLUR_OK; }
-    std::vector<uint16_t> map((cols + 31) / 32);
-    const int sets = fx_fragment_sets(mt->host_taps.data(), mt->pad, nkb, cols, map.data(), nullptr);
-    std::vector<uint16_t> fr(static_cast<size_t>(sets) * 2 * nkb * 512);
-    fx_fragment_sets(mt->host_taps.data(), mt->pad, nkb, cols, map.data(), fr.data());
-    FxTables t;
-    HIP_TRY(ctx, hipMalloc(&t.frags, fr.size() * sizeof(uint16_t)));
-    HIP_TRY(ctx, hipMemcpy(t.frags, fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&t.tilemap), map.size() * sizeof(uint16_t)));
-    HIP_TRY(ctx, hipMemcpy(t.tilemap, map.data(), map.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-    *out = &(ctx->fx_tables[key] = t);
     return BLUR_OK;
 }
 
@@ -1106,7 +1080,6 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         if (static_cast<long long>(rows) * cols * 3 >= (1ll << 32)) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: frame too large for 32-bit offsets");
         if ((cols & 3) != 0) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: the image width must be a multiple of 4");
         if (int rc = mx_get_tables(ctx, fe->nkb, sigma, p.sz, ck, &p.mxt)) return rc;
-        if (int rc = fx_get_tables(ctx, p.mxt, fe->nkb, cols, &p.fxt)) return rc;
         p.fx = fe;
         p.mx_quirk = quirk;
         p.frame_elems = 0;
@@ -1395,10 +1368,6 @@ int blur_ctx_destroy(blur_ctx* ctx)
         (void)hipFree(kv.second.frags_row); (void)hipFree(kv.second.frags_col);
         (void)hipFree(kv.second.taps_row); (void)hipFree(kv.second.taps_col);
     }
-    for (auto& kv : ctx->fx_tables) {
-        if (kv.second.frags) (void)hipFree(kv.second.frags);
-        if (kv.second.tilemap) (void)hipFree(kv.second.tilemap);
-    }
     if (ctx->mx_sums) (void)hipFree(ctx->mx_sums);
     if (ctx->mx_terms) (void)hipFree(ctx->mx_terms);
     if (ctx->work) (void)hipFree(reinterpret_cast<char*>(ctx->work) - kWorkGuard);
@@ -1524,7 +1493,6 @@ static int run_mx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
 // both passes in one kernel on the matrix cores (fx_kernels.hpp): no intermediate in memory
 static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes, int rows, int cols, const Prepared& p)
 {
-    if (p.mx_quirk) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: quirk terms not wired yet");
     const size_t px = static_cast<size_t>(rows) * cols;
     // in place (the reference's own calling convention, Source.cpp:429,567): a strip reads its neighbours' columns and the rows
     // below while they are being written, so the frames are read from a copy in the workspace
@@ -1538,8 +1506,40 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     FxGeom g{ rows, cols, p.sz.pad, nframes, 0, (rows + 31) / 32 };
     g.aligned = ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 3) == 0) ? 1 : 0;
     if (!g.aligned) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: frame pointers must be 4-byte aligned");
+    const int nkb = p.fx->nkb, pada = 8 * (nkb - 2), nt = (nkb - 1) / 2;
+    const int qrows = 32 * (g.ntiles + nt), qpitch = (3 * cols + 31) & ~31;
+    float *qrow = nullptr, *qcol = nullptr;
+    if (p.mx_quirk) {
+        // scratch per frame: srow_part int [batches][rows][3]; cpart int [bands][3 cols]; then floats: qrow [3][qrows], qcol [qpitch]
+        const int nbands = (rows + kFxSumRows - 1) / kFxSumRows, nbatches = (cols / 4 + 255) / 256;
+        const size_t n_srow = static_cast<size_t>(nbatches) * rows * 3, n_cpart = static_cast<size_t>(nbands) * 3 * cols;
+        const size_t sums_bytes = (n_srow + n_cpart) * sizeof(int) * nframes + 64;
+        const size_t terms_bytes = (static_cast<size_t>(3) * qrows + qpitch) * sizeof(float) * nframes + 64;
+        if (ctx->mx_sums_bytes < sums_bytes) {
+            if (ctx->mx_sums) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->mx_sums)); ctx->mx_sums = nullptr; ctx->mx_sums_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mx_sums), sums_bytes));
+            ctx->mx_sums_bytes = sums_bytes;
+        }
+        if (ctx->mx_terms_bytes < terms_bytes) {
+            if (ctx->mx_terms) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->mx_terms)); ctx->mx_terms = nullptr; ctx->mx_terms_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mx_terms), terms_bytes));
+            ctx->mx_terms_bytes = terms_bytes;
+        }
+        int* srow = ctx->mx_sums;
+        int* cpart = srow + ((n_srow * nframes + 3) & ~static_cast<size_t>(3));       // 16-byte aligned: int4 stores
+        qrow = ctx->mx_terms;
+        qcol = qrow + static_cast<size_t>(3) * qrows * nframes;
+        { TimedLaunch t(ctx, 1, nframes);
+          hipLaunchKernelGGL(fx_altsums, dim3(nbands, nbatches, nframes), dim3(256), 0, ctx->stream, d_src, srow, cpart, rows, cols, p.sz.pad, nbands, nbatches);
+          HIP_TRY(ctx, hipGetLastError());
+          const int nrb = (qrows + 255) / 256, ncb = (qpitch + 255) / 256;
+          const size_t lds = static_cast<size_t>(3) * (256 / 3 + 2 + 2 * p.sz.pad + 2) * sizeof(int);
+          hipLaunchKernelGGL(fx_quirk_terms, dim3(nrb + ncb, nframes), dim3(256), lds, ctx->stream, srow, cpart, p.mxt->taps_row, qrow, qcol, rows, cols, p.sz.pad, pada,
+                             qrows, qpitch, nbands, nbatches, nrb, p.mxt->dr, p.mxt->dc);
+          HIP_TRY(ctx, hipGetLastError()); }
+    }
     { TimedLaunch t(ctx, 0, nframes);
-      HIP_TRY(ctx, p.fx->blur_u8(ctx->stream, d_src, d_dst, p.fxt->frags, p.fxt->tilemap, g, ctx->num_cus, nullptr, nullptr, 0)); }
+      HIP_TRY(ctx, p.fx->blur_u8(ctx->stream, d_src, d_dst, p.mxt->frags_row, g, ctx->num_cus, qrow, qcol, qpitch)); }
     return BLUR_OK;
 }
 

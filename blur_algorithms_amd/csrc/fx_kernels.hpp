@@ -30,6 +30,13 @@
 #pragma once
 #include "mx_kernels.hpp"
 
+#ifndef FX_SGB_A
+#define FX_SGB_A 6
+#endif
+#ifndef FX_SGB_B
+#define FX_SGB_B 5
+#endif
+
 namespace blur_amd {
 
 struct FxGeom {
@@ -47,8 +54,7 @@ template <int NKB> struct FxCfg {
     static constexpr int NT = (NKB - 1) / 2;                          // live accumulator tiles per channel = steps per unrolled round
     static constexpr int BUF = 3 * 32 * PW * 2;                       // bytes of one window buffer
     static constexpr int QOFF = 2 * BUF;                              // qrow stage: [2][3][32] floats
-    static constexpr int FOFF = QOFF + 2 * 96 * 4;                    // the column pass's Toeplitz fragments: [hi, lo][NKB][64] x 16 bytes
-    static constexpr int LDS = FOFF + 2 * NKB * 1024;
+    static constexpr int LDS = QOFF + 2 * 96 * 4;
 };
 
 // x as binary16: the byte in the low half of a binary16 is the SUBNORMAL x * 2^-24 -- the matrix cores take subnormal
@@ -97,7 +103,7 @@ __device__ __forceinline__ uint32_t fx_quad_transpose(uint32_t p, uint32_t sel1,
 template <int NKB, bool QUIRK>
 __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, FxGeom g,
                                                      int chunks, int tps, int nseg, int ntasks, const float* __restrict__ qrow, const float* __restrict__ qcol,
-                                                     int qpitch, const uint16_t* __restrict__ tilemap)
+                                                     int qpitch)
 {
     using C = FxCfg<NKB>;
     constexpr int PADA = C::PADA, PW = C::PW, NT = C::NT, PER = C::PER;
@@ -117,25 +123,13 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 
     // hi halves of the fragments in registers, lo halves in LDS (one ds_read_b128 per use: the register file holds the
     // 15 accumulator tiles instead)
-    // Reflect-101 along the rows is folded into the ROW pass's fragments: a tile whose window reaches over the image's left or
-    // right edge has its own fragment set in which a mirrored tap is added to the tap of the pixel it mirrors (host_math.hpp:
-    // fx_fragment_sets); window positions outside the image carry zero taps, whatever the loads return there.
-    // tilemap[tile column] = set.  The row pass's fragments (hi and lo halves) stay in registers; the column pass's -- always
-    // set 0: its border rows are real rows of V -- are read from LDS, one ds_read_b128 per use.
+    // the Toeplitz fragments (hi and lo halves) serve both passes: B operand of the row pass, A operand of the column pass
     mx_half8 th[NKB], tl[NKB];
-    {
-        const int tt = 4 * xc + wave, set = tt < (g.cols + 31) / 32 ? tilemap[tt] : 0;
-        const mx_half8* fs = frags + static_cast<size_t>(set) * 2 * NKB * 64;
 #pragma unroll
-        for (int kb = 0; kb < NKB; ++kb) {
-            th[kb] = fs[kb * 64 + lane];
-            tl[kb] = fs[(NKB + kb) * 64 + lane];
-        }
-        for (int i = tid; i < 2 * NKB * 64; i += 256) reinterpret_cast<mx_half8*>(fx_lds + C::FOFF)[i] = frags[i];
+    for (int kb = 0; kb < NKB; ++kb) {
+        th[kb] = frags[kb * 64 + lane];
+        tl[kb] = frags[(NKB + kb) * 64 + lane];
     }
-    const mx_half8* cfp = reinterpret_cast<const mx_half8*>(fx_lds + C::FOFF) + lane;
-#define ch_(d) cfp[(d) * 64]
-#define cl_(d) cfp[(NKB + (d)) * 64]
 
     // per-lane constants of the emission: quad transposes and the store address
     const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
@@ -171,19 +165,39 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     FxRaw<NKB> raw;
     float qraw = 0.f;
     // staging in three chunks of three 12-byte groups: commit chunk j of window s, then refill the registers with window s + 1
-    // (the frame as a buffer resource: a group that starts left of the image or runs past the frame's end is out of bounds and
-    // reads as zero; inside, a group past a row's end reads the next row's first pixels -- zero taps either way)
+    // Reflect-101 along the rows (Source.cpp:525-529) is done by the loads: the image width is a multiple of 4, so a 12-byte group
+    // of the window lies inside the image or outside it, and a group outside is the pixel-reversed copy of a group inside, 3 bytes
+    // (left) or 1 byte (right) off the dword grid -- gfx950 loads it unaligned; the commit reverses its pixels (other selectors of
+    // the same v_perm_b32).  Only the chunks at the two edges (uniform per workgroup) run that code.  The frame is a buffer
+    // resource: mirrored groups beyond the reach of the taps (tiny images) may fall outside it and read as zero.
     const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, static_cast<uint32_t>(g.rows) * g.cols * 3u, kMxRsrcWord3);
+    const bool edge = x0 - PADA < 0 || x0 + kFxChunk + PADA > g.cols;      // uniform
+    auto group_x = [&](int k, bool& mir) __attribute__((always_inline)) {  // first source pixel of group k of this thread
+        const int X = x0 - PADA + 4 * ((tid & 7) + 8 * k);
+        mir = X < 0 || X >= g.cols;
+        return X < 0 ? -X - 3 : (X >= g.cols ? 2 * g.cols - 5 - X : X);
+    };
     auto issue_chunk = [&](int s, int j) __attribute__((always_inline)) {
         const int row = tid >> 3, g0 = tid & 7;
         const int r = mx_refl(32 * s - PADA + row, g.rows);
-        const uint32_t off = (static_cast<uint32_t>(r) * g.cols + static_cast<uint32_t>(x0 - PADA + 4 * g0)) * 3u;
+        typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+        if (!edge) {
+            const uint32_t off = (static_cast<uint32_t>(r) * g.cols + static_cast<uint32_t>(x0 - PADA + 4 * g0)) * 3u;
 #pragma unroll
-        for (int k = 3 * j; k < 3 * j + 3 && k < PER; ++k) {
-            typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-            const bool in = (C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8;
-            const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rimg, in ? off + 96u * k : off, 0, 0);
-            raw.d[k][0] = t[0]; raw.d[k][1] = t[1]; raw.d[k][2] = t[2];
+            for (int k = 3 * j; k < 3 * j + 3 && k < PER; ++k) {
+                const bool in = (C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8;
+                const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rimg, in ? off + 96u * k : off, 0, 0);
+                raw.d[k][0] = t[0]; raw.d[k][1] = t[1]; raw.d[k][2] = t[2];
+            }
+        } else {
+            const uint32_t rowoff = static_cast<uint32_t>(r) * g.cols * 3u;
+#pragma unroll
+            for (int k = 3 * j; k < 3 * j + 3 && k < PER; ++k) {
+                bool mir;
+                const int xs = group_x(k, mir);
+                const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rimg, rowoff + 3u * static_cast<uint32_t>(xs), 0, 0);
+                raw.d[k][0] = t[0]; raw.d[k][1] = t[1]; raw.d[k][2] = t[2];
+            }
         }
         if (QUIRK && j == 0 && tid < 96) {
             const int c = tid >> 5, re = 32 * s + (tid & 31);
@@ -196,18 +210,23 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #pragma unroll
         for (int k = 3 * j; k < 3 * j + 3 && k < PER; ++k) {
             if ((C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8) {
+                bool mir = false;
+                if (edge) (void)group_x(k, mir);
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
+                    // window pixels (0, 1) and (2, 3) of the group: source bytes (c, 3 + c) and (6 + c, 9 + c); mirrored: (9 + c, 6 + c) and (3 + c, c)
+                    auto pick = [&](int B0, int B1) __attribute__((always_inline)) {
+                        const int da = B1 >> 2, db = B0 >> 2;
+                        const uint32_t sel = fx_sel1(B0, da, db) | (0x0cu << 8) | (fx_sel1(B1, da, db) << 16) | (0x0cu << 24);
+                        return __builtin_amdgcn_perm(raw.d[k][da], raw.d[k][db], sel);
+                    };
                     uint2 wd;
-                    {   // pixels 0, 1: bytes c, 3 + c
-                        const int B0 = c, B1 = 3 + c, da = B1 >> 2, db = B0 >> 2;
-                        const uint32_t sel = fx_sel1(B0, da, db) | (0x0cu << 8) | (fx_sel1(B1, da, db) << 16) | (0x0cu << 24);
-                        wd.x = __builtin_amdgcn_perm(raw.d[k][da], raw.d[k][db], sel);
-                    }
-                    {   // pixels 2, 3: bytes 6 + c, 9 + c
-                        const int B0 = 6 + c, B1 = 9 + c, da = B1 >> 2, db = B0 >> 2;
-                        const uint32_t sel = fx_sel1(B0, da, db) | (0x0cu << 8) | (fx_sel1(B1, da, db) << 16) | (0x0cu << 24);
-                        wd.y = __builtin_amdgcn_perm(raw.d[k][da], raw.d[k][db], sel);
+                    wd.x = pick(c, 3 + c);
+                    wd.y = pick(6 + c, 9 + c);
+                    if (edge) {
+                        const uint32_t mx_ = pick(9 + c, 6 + c), my_ = pick(3 + c, c);
+                        wd.x = mir ? mx_ : wd.x;
+                        wd.y = mir ? my_ : wd.y;
                     }
                     *reinterpret_cast<uint2*>(base + c * 32 * PW + 32 * k) = wd;
                 }
@@ -276,7 +295,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
             constexpr int d = NKB - 1;
             const int slot = qs % NT;
             mx_float16 t = acc[c][slot];
-            const mx_half8 fh = ch_(d), fl = cl_(d);
+            const mx_half8 fh = th[d], fl = tl[d];
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, v1[0], t, 0, 0, 0);
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, v1[0], t, 0, 0, 0);
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, v2[0], t, 0, 0, 0);
@@ -298,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
         for (int dd = 2; dd < NKB + 1; ++dd) {
             const int d = dd >= NKB - 1 ? dd - (NKB - 1) : dd, b = d & 1, a2 = d >> 1, slot = (qs - a2 + 2 * NT) % NT;
             mx_float16 t = d == 0 ? zero : acc[c][slot];
-            const mx_half8 fh = ch_(d), fl = cl_(d);
+            const mx_half8 fh = th[d], fl = tl[d];
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, v1[b], t, 0, 0, 0);
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, v1[b], t, 0, 0, 0);
             t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, v2[b], t, 0, 0, 0);
@@ -352,17 +371,42 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
                 const int hb = (3 * qs + c) & 1;                           // hand-off buffer (static: see the copy after the round)
                 // ---- phase A: the next product's row pass; staging of window s + 2 (chunks in A(s,2), A(s+1,0), A(s+1,1)); stores
                 if (c == 2) __syncthreads();                               // window s + 1 complete, window s no longer read
+#ifndef FX_NOSB
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 if (c == 2) rowpass(cur ^ 1, 0); else rowpass(cur, c + 1);
                 if (c == 2) { commit_chunk(cur, 0); issue_chunk(s + 3, 0); }
                 else if (c == 0) { commit_chunk(cur ^ 1, 1); issue_chunk(s + 2, 1); }
                 else { commit_chunk(cur ^ 1, 2); issue_chunk(s + 2, 2); }
                 if (c == 0 && s - 1 - NT >= tile0 && s > s0) store_tile(s - 1 - NT);
+#ifdef FX_SGB
+                // the order the scheduler is asked for: window reads three blocks ahead, staging spread between the products
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+#pragma unroll
+                for (int i = 0; i < NKB; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, FX_SGB_A, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                }
+#endif
+#ifndef FX_NOSB
                 __builtin_amdgcn_sched_barrier(0);
+#endif
                 // ---- phase B: this product's column pass; the next product's hand-off; this tile's bytes
                 colpass(hb, c, qs);
                 if (c == 2) split(hb ^ 1, cur ^ 1, 0); else split(hb ^ 1, cur, c + 1);
+#ifdef FX_SGB
+                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+#pragma unroll
+                for (int i = 0; i < 3 * NKB - 3; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x002, FX_SGB_B, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                }
+#endif
+#ifndef FX_NOSB
                 __builtin_amdgcn_sched_barrier(0);
+#endif
             }
         }
         // a round is 3 NT products, an odd number: its last hand-off went to buffer 1, the next round starts reading buffer 0
@@ -374,17 +418,192 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     if (s1 - 1 - NT >= tile0) store_tile(s1 - 1 - NT);
 }
 
-#undef ch_
-#undef cl_
+// ---------------------------------------------------------------------------------------------------------------
+// The Nyquist-slot quirk (Source.cpp:420-425; derivation in mx_kernels.hpp) for the fused kernel.  With wx, wy the alternating
+// weights of a reflect-101 padded line (mx_alt_weight):
+//     V'[r][x]  = V[r][x] + dr (-1)^(x+pad) Srow(r),            Srow(r) = sum_x wx(x) img[r][x]                       (integers)
+//     out[r][x] = colconv(V')[r][x] + dc (-1)^(r+pad) Scol(x),  Scol(x) = sum_r wy(r) V'[r][x]
+//                                                                       = rowconv(Ccol)(x) + dr (-1)^(x+pad) Z
+//     Ccol(x) = sum_r wy(r) img[r][x]  (integers; the row convolution and the weighted column sum commute),  Z = sum_r wy(r) Srow(r)
+// fx_altsums reads the image once and leaves Srow and, per band of rows, the partial Ccol; fx_quirk_terms turns them into
+// qrow[f][c][re] = dr (-1)^pad Srow[refl(re - PADA)][c] and qcol[f][3 x + c] = dc (-1)^pad Scol, which the fused kernel adds
+// as qrow (-1)^x (to V, before the hand-off) and qcol (-1)^r (to the output, before the truncation).
+#ifdef BLUR_FX_QUIRK_KERNELS   // engine.hip only: plain (non-template) kernels must live in one translation unit
+constexpr int kFxSumRows = 32;          // image rows per band (packed 16-bit column sums: 32 x 3 x 255 < 65536)
+
+// sum over the 16 lanes of a DPP row, valid in every lane of the row
+__device__ __forceinline__ int fx_row16_sum(int v)
+{
+    v += __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);    // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);    // row_mirror
+    return v;
+}
+
+// grid (bands of kFxSumRows rows, batches of 256 twelve-byte groups = 1024 pixel columns, frames), 256 threads: a thread owns one
+// group (4 pixels) of every row of the band, eight rows of loads in flight; cols % 4 == 0, frames 4-byte aligned.
+//   srow_part[f][batch][r][c]  sum over the batch's pixels of wx(x) img[r][x][c]
+//   cpart[f][band][3 x + c]    sum over the band's rows of wy(r) img[r][x][c]
+__global__ __launch_bounds__(256) void fx_altsums(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, int rows, int cols, int pad,
+                                                  int nbands, int nbatches)
+{
+    __shared__ int sred[kFxSumRows][3];
+    const int f = blockIdx.z, batch = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
+    const uint8_t* img = src + static_cast<size_t>(f) * rows * cols * 3;
+    const int groups = cols / 4, r0 = band * kFxSumRows, r1 = min(r0 + kFxSumRows, rows);
+    const int gi = batch * 256 + tid, x = 4 * gi;
+    const bool act = gi < groups;
+    if (tid < kFxSumRows * 3) (&sred[0][0])[tid] = 0;
+    __syncthreads();
+    const int flip = (pad & 1) ? -1 : 1;
+    const bool plain = x > pad && x + 3 < cols - 1 - pad;                 // no pixel of the group is mirrored: weights +-1 by parity
+    int wq[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wq[q] = act ? mx_alt_weight(x + q, cols, pad) : 0;
+    uint32_t accp[6], accn[6];                                            // packed 16-bit sums of the rows with positive / negative wy
+#pragma unroll
+    for (int j = 0; j < 6; ++j) accp[j] = accn[j] = 0;
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    const uint8_t* col0 = img + 12 * static_cast<size_t>(act ? gi : 0);
+    for (int rb = r0; rb < r1; rb += 8) {
+        u3 d[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = min(rb + i, r1 - 1);
+            d[i] = *reinterpret_cast<const u3*>(col0 + static_cast<size_t>(r) * cols * 3);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = rb + i;
+            if (r < r1) {                                                    // uniform
+                const int wy = mx_alt_weight(r, rows, pad);
+                int s[3] = { 0, 0, 0 };
+                if (plain) {
+                    const int e0 = static_cast<int>(d[i][0] ^ 0x80808080u), e1 = static_cast<int>(d[i][1] ^ 0x80808080u), e2 = static_cast<int>(d[i][2] ^ 0x80808080u);
+                    // bytes (pixel q, channel c) = 3 q + c of the group, signs + - + - over q; the offset 128 cancels (weights sum to 0)
+                    int t0 = __builtin_amdgcn_sdot4(e0, static_cast<int>(0xff000001u), 0, false);
+                    t0 = __builtin_amdgcn_sdot4(e1, 0x00010000, t0, false);
+                    t0 = __builtin_amdgcn_sdot4(e2, 0x0000ff00, t0, false);
+                    int t1 = __builtin_amdgcn_sdot4(e0, 0x00000100, 0, false);
+                    t1 = __builtin_amdgcn_sdot4(e1, 0x010000ff, t1, false);
+                    t1 = __builtin_amdgcn_sdot4(e2, 0x00ff0000, t1, false);
+                    int t2 = __builtin_amdgcn_sdot4(e0, 0x00010000, 0, false);
+                    t2 = __builtin_amdgcn_sdot4(e1, 0x0000ff00, t2, false);
+                    t2 = __builtin_amdgcn_sdot4(e2, static_cast<int>(0xff000001u), t2, false);
+                    s[0] = flip * t0; s[1] = flip * t1; s[2] = flip * t2;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c) {
+                            const int byte = 3 * q + c;
+                            s[c] += wq[q] * static_cast<int>((d[i][byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+                        }
+                }
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int t = fx_row16_sum(act ? s[c] : 0);
+                    if ((tid & 15) == 0) atomicAdd(&sred[r - r0][c], t);
+                }
+                // column sums: bytes 0, 2 of each dword in one packed pair, bytes 1, 3 in the other; |wy| = 1, 2 or 3 (uniform)
+                const uint32_t aw = static_cast<uint32_t>(wy < 0 ? -wy : wy);
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const uint32_t lo = (d[i][j] & 0x00ff00ffu) * aw, hi = ((d[i][j] >> 8) & 0x00ff00ffu) * aw;
+                    if (wy > 0) { accp[2 * j] += lo; accp[2 * j + 1] += hi; }
+                    else { accn[2 * j] += lo; accn[2 * j + 1] += hi; }
+                }
+            }
+        }
+    }
+    if (act) {
+        int o[12];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            o[4 * j] = static_cast<int>(accp[2 * j] & 0xffffu) - static_cast<int>(accn[2 * j] & 0xffffu);
+            o[4 * j + 2] = static_cast<int>(accp[2 * j] >> 16) - static_cast<int>(accn[2 * j] >> 16);
+            o[4 * j + 1] = static_cast<int>(accp[2 * j + 1] & 0xffffu) - static_cast<int>(accn[2 * j + 1] & 0xffffu);
+            o[4 * j + 3] = static_cast<int>(accp[2 * j + 1] >> 16) - static_cast<int>(accn[2 * j + 1] >> 16);
+        }
+        int4* dstp = reinterpret_cast<int4*>(cpart + (static_cast<size_t>(f) * nbands + band) * (3 * cols) + 12 * gi);
+        dstp[0] = make_int4(o[0], o[1], o[2], o[3]);
+        dstp[1] = make_int4(o[4], o[5], o[6], o[7]);
+        dstp[2] = make_int4(o[8], o[9], o[10], o[11]);
+    }
+    __syncthreads();
+    if (tid < (r1 - r0) * 3) srow_part[((static_cast<size_t>(f) * nbatches + batch) * rows + r0) * 3 + tid] = (&sred[0][0])[tid];
+}
+
+// grid (row blocks + column blocks, frames), 256 threads.  Row blocks: qrow for 256 rows of V each.  Column blocks: qcol for 256
+// values e = 3 x + c each -- Ccol over the bands into LDS (with the taps' reach on both sides), the row convolution in double.
+// Every column block sums Z itself (3 rows values, integers).   taps: 2 pad + 1 floats, centre at pad.
+__global__ __launch_bounds__(256) void fx_quirk_terms(const int* __restrict__ srow_part, const int* __restrict__ cpart, const float* __restrict__ taps,
+                                                      float* __restrict__ qrow, float* __restrict__ qcol, int rows, int cols, int pad, int pada, int qrows, int qpitch,
+                                                      int nbands, int nbatches, int nrowblocks, float dr, float dc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fxq_lds[];
+    __shared__ double zs[3][256];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const double sp = (pad & 1) ? -1.0 : 1.0;
+    const int* sr = srow_part + static_cast<size_t>(f) * nbatches * rows * 3;
+    auto srow = [&](int r, int c) {                  // Srow: the batches' parts added up (integers)
+        int v = 0;
+        for (int b = 0; b < nbatches; ++b) v += sr[(static_cast<size_t>(b) * rows + r) * 3 + c];
+        return v;
+    };
+    if (static_cast<int>(blockIdx.x) < nrowblocks) {
+        const int re = blockIdx.x * 256 + tid;
+        if (re < qrows) {
+            const int r = mx_refl(re - pada, rows);
+            for (int c = 0; c < 3; ++c) qrow[(static_cast<size_t>(f) * 3 + c) * qrows + re] = static_cast<float>(static_cast<double>(dr) * sp * srow(r, c));
+        }
+        return;
+    }
+    double z[3] = { 0, 0, 0 };
+    for (int r = tid; r < rows; r += 256) {
+        const double wy = static_cast<double>(mx_alt_weight(r, rows, pad));
+        for (int c = 0; c < 3; ++c) z[c] += wy * srow(r, c);
+    }
+    for (int c = 0; c < 3; ++c) zs[c][tid] = z[c];
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if (tid < o) for (int c = 0; c < 3; ++c) zs[c][tid] += zs[c][tid + o];
+        __syncthreads();
+    }
+    const int e0 = (blockIdx.x - nrowblocks) * 256;
+    // pixels whose column sums this block's outputs read: [xa, xb] inside the image (reflect-101 maps into it)
+    const int xa = max(0, e0 / 3 - pad), xb = min(cols - 1, (e0 + 255) / 3 + pad), nval = 3 * (xb - xa + 1);
+    int* cc = reinterpret_cast<int*>(fxq_lds);
+    const int* cp = cpart + static_cast<size_t>(f) * nbands * (3 * cols) + 3 * xa;
+    for (int i = tid; i < nval; i += 256) {
+        int sum = 0;
+        for (int b = 0; b < nbands; ++b) sum += cp[static_cast<size_t>(b) * (3 * cols) + i];
+        cc[i] = sum;
+    }
+    __syncthreads();
+    const int e = e0 + tid;
+    if (e >= qpitch) return;
+    const int x = e / 3, c = e - 3 * x;
+    float out = 0.f;
+    if (x < cols) {
+        double acc = 0;
+        for (int t = -pad; t <= pad; ++t) acc += static_cast<double>(taps[t + pad]) * cc[3 * (mx_refl(x + t, cols) - xa) + c];
+        const double sx = ((x + pad) & 1) ? -1.0 : 1.0;
+        out = static_cast<float>(static_cast<double>(dc) * sp * (acc + static_cast<double>(dr) * sx * zs[c][0]));
+    }
+    qcol[static_cast<size_t>(f) * qpitch + e] = out;
+}
+#endif  // BLUR_FX_QUIRK_KERNELS
+
 // ---- launcher ----------------------------------------------------------------------------------------------------------
 struct FxEntry {
     int nkb;
-    hipError_t (*blur_u8)(hipStream_t, const uint8_t* src, uint8_t* dst, const void* frags, const uint16_t* tilemap, FxGeom g, int num_cus, const float* qrow, const float* qcol,
-                          int qpitch);
+    hipError_t (*blur_u8)(hipStream_t, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const float* qrow, const float* qcol, int qpitch);
 };
 
-template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, uint8_t* dst, const void* frags, const uint16_t* tilemap, FxGeom g, int num_cus,
-                                           const float* qrow, const float* qcol, int qpitch)
+template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const float* qrow,
+                                           const float* qcol, int qpitch)
 {
     using C = FxCfg<NKB>;
     const int chunks = (g.cols + kFxChunk - 1) / kFxChunk;
@@ -410,10 +629,10 @@ template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, u
     }
     if (qrow)
         hipLaunchKernelGGL((fx_blur_u8<NKB, true>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg,
-                           static_cast<int>(ntasks), qrow, qcol, qpitch, tilemap);
+                           static_cast<int>(ntasks), qrow, qcol, qpitch);
     else
         hipLaunchKernelGGL((fx_blur_u8<NKB, false>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg,
-                           static_cast<int>(ntasks), qrow, qcol, qpitch, tilemap);
+                           static_cast<int>(ntasks), qrow, qcol, qpitch);
     return hipGetLastError();
 }
 

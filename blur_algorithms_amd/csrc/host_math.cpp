@@ -368,46 +368,4 @@ void mx_fragments(const float* taps, int pad, int nkb, uint16_t* out)
             }
 }
 
-int fx_fragment_sets(const float* taps, int pad, int nkb, int cols, uint16_t* tilemap, uint16_t* out)
-{
-    const int pada = 8 * (nkb - 2), ntx = (cols + 31) / 32, win = 16 * nkb;
-    const size_t set_elems = static_cast<size_t>(2) * nkb * 512;
-    const double scale = std::ldexp(1.0, kMxScaleLog2);
-    if (out) mx_fragments(taps, pad, nkb, out);
-    int sets = 1;
-    std::vector<double> tz(static_cast<size_t>(win) * 32);
-    for (int tile = 0; tile < ntx; ++tile) {
-        const int xt0 = 32 * tile;
-        // no border inside the reach of the taps of any of the tile's outputs (outputs beyond the image do not count)
-        const int last = std::min(xt0 + 31, cols - 1);
-        if (xt0 - pad >= 0 && last + pad <= cols - 1 && xt0 + 31 <= cols - 1) { tilemap[tile] = 0; continue; }
-        tilemap[tile] = static_cast<uint16_t>(sets);
-        if (out) {
-            std::fill(tz.begin(), tz.end(), 0.0);
-            for (int o = 0; o < 32 && xt0 + o < cols; ++o)
-                for (int t = -pad; t <= pad; ++t) {
-                    int xs = xt0 + o + t;
-                    if (xs < 0) xs = -xs;
-                    if (xs >= cols) xs = 2 * (cols - 1) - xs;
-                    const int w = xs - (xt0 - pada);
-                    if (xs < 0 || xs >= cols || w < 0 || w >= win) continue;     // (cannot happen for pad <= cols - 1)
-                    tz[static_cast<size_t>(w) * 32 + o] += static_cast<double>(taps[t + pad]);
-                }
-            uint16_t* dst = out + set_elems * sets;
-            for (int kb = 0; kb < nkb; ++kb)
-                for (int l = 0; l < 64; ++l)
-                    for (int j = 0; j < 8; ++j) {
-                        const int w = 16 * kb + 8 * (l >> 5) + j, o = l & 31;
-                        const float v = static_cast<float>(tz[static_cast<size_t>(w) * 32 + o] * scale);
-                        const uint16_t hi = f32_to_f16(v), lo = f32_to_f16(v - f16_to_f32(hi));
-                        const size_t e = (static_cast<size_t>(kb) * 64 + l) * 8 + j;
-                        dst[e] = hi;
-                        dst[static_cast<size_t>(nkb) * 512 + e] = lo;
-                    }
-        }
-        ++sets;
-    }
-    return sets;
-}
-
 }  // namespace blur_amd

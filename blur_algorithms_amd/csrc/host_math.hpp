@@ -100,13 +100,4 @@ inline int mx_nkb(int pad) { return 2 + mx_pada(pad) / 8; }
 // = f16(tap * 2^14), part 1 = lo = f16(tap * 2^14 - hi).  taps: 2 pad + 1 floats, centre at index pad.
 void mx_fragments(const float* taps, int pad, int nkb, uint16_t* out);
 
-// ---- fused matrix-core engine (fx_kernels.hpp) -------------------------------------------------------------------
-// Fragment sets for an image of `cols` columns.  Set 0 is mx_fragments (no border inside the tile's window).  Every tile
-// column (32 outputs from xt0 = 32 tile) whose window reaches over the image's left or right edge gets a set of its own with
-// reflect-101 (Source.cpp:525-529) FOLDED IN: Tz'[w][o] = sum of taps[t] over the t with refl101(xt0 + o + t) = xt0 - PADA + w,
-// so a mirrored pixel's tap is added to the tap of the pixel it mirrors and window positions outside the image carry zero
-// (outputs beyond the image too).  tilemap: (cols + 31) / 32 entries, the set of each tile column.  Returns the number of sets;
-// out (nullptr: only count and map): [sets][2][nkb][64][8] binary16.  Requires pad <= cols - 1 (one reflection).
-int fx_fragment_sets(const float* taps, int pad, int nkb, int cols, uint16_t* tilemap, uint16_t* out);
-
 }  // namespace blur_amd

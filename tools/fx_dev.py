@@ -18,7 +18,7 @@ nf = int(args[0]) if args else 8
 ctx = B.BlurContext(0)
 g = torch.Generator(device="cuda").manual_seed(1)
 if check:
-    for rows, cols, sigma, n in ((200, 300, 20.0, 1), (256, 384, 20.0, 2), (332, 516, 18.5, 1), (70, 68, 20.0, 1), (66, 132, 20.0, 3), (1080, 1920, 20.0, 1), (2160, 3840, 20.0, 2), (90, 4004, 19.0, 1)):
+    for rows, cols, sigma, n in ((100, 100, 20.0, 1), (100, 100, 20.0, 2), (70, 68, 20.0, 2), (100, 300, 20.0, 1), (100, 128, 20.0, 1), (160, 100, 20.0, 1), (80, 200, 20.0, 1), (300, 72, 20.0, 1), (67, 256, 19.0, 2), (200, 300, 20.0, 1), (256, 384, 20.0, 2), (332, 516, 18.5, 1), (70, 68, 20.0, 1), (66, 132, 20.0, 3), (1080, 1920, 20.0, 1), (2160, 3840, 20.0, 2), (90, 4004, 19.0, 1)):
         fr = torch.randint(0, 256, (n, rows, cols, 3), dtype=torch.uint8, device="cuda", generator=g)
         a = ctx.pffft_(fr, sigma, out=torch.empty_like(fr), nyquist_quirk=quirk, engine="matrix")
         b = ctx.pffft_(fr, sigma, out=torch.empty_like(fr), nyquist_quirk=quirk, engine="fused")
@@ -40,4 +40,12 @@ for eng in ("fused", "matrix", "fused"):
         ctx.pffft_(frames, sigma, out=out, nyquist_quirk=quirk, engine=eng)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
-    print("engine %-8s quirk %d: %.3f ms/step  %.1f us/frame  %.1f GP/s" % (eng, quirk, dt * 1e3, dt / nf * 1e6, nf * rows * cols / dt / 1e9), flush=True)
+    ctx.timing_enable(True)
+    ctx.timing()
+    for _ in range(n):
+        ctx.pffft_(frames, sigma, out=out, nyquist_quirk=quirk, engine=eng)
+    torch.cuda.synchronize()
+    t = ctx.timing()
+    ctx.timing_enable(False)
+    print("engine %-8s quirk %d: %.3f ms/step  %.1f us/frame  %.1f GP/s   [events: slot0 %.1f us/frame, slot1 %.1f us/frame]" % (
+        eng, quirk, dt * 1e3, dt / nf * 1e6, nf * rows * cols / dt / 1e9, t["row_ms"] / max(t["row_frames"], 1) * 1e3, t["col_ms"] / max(t["col_frames"], 1) * 1e3), flush=True)
