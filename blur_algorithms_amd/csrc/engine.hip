@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -636,6 +637,8 @@ struct blur_ctx {
     std::map<std::tuple<int, int, int, int, uint64_t>, float*> wr_spectra;   // (n, n_ref, ksize | -1, quirk, sigma bits | hash)
     // matrix-core engine (mx_kernels.hpp): Toeplitz fragments + taps per kernel, integer sums and float terms of the quirk
     std::map<std::tuple<int, int, int, int, int, uint64_t>, MxTables> mx_tables;   // (ksize | -1, pad, nkb, n_row, n_col, sigma bits | hash)
+    uint8_t* fx_strips = nullptr;   // fused kernel: the edge chunks' windows with the mirrored pixels in place
+    size_t fx_strips_bytes = 0;
     int* mx_sums = nullptr;
     size_t mx_sums_bytes = 0;
     float* mx_terms = nullptr;
@@ -1368,6 +1371,7 @@ int blur_ctx_destroy(blur_ctx* ctx)
         (void)hipFree(kv.second.frags_row); (void)hipFree(kv.second.frags_col);
         (void)hipFree(kv.second.taps_row); (void)hipFree(kv.second.taps_col);
     }
+    if (ctx->fx_strips) (void)hipFree(ctx->fx_strips);
     if (ctx->mx_sums) (void)hipFree(ctx->mx_sums);
     if (ctx->mx_terms) (void)hipFree(ctx->mx_terms);
     if (ctx->work) (void)hipFree(reinterpret_cast<char*>(ctx->work) - kWorkGuard);
@@ -1503,17 +1507,33 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         HIP_TRY(ctx, hipMemcpyAsync(ctx->work, d_src, px * 3 * nframes, hipMemcpyDeviceToDevice, ctx->stream));
         d_src = reinterpret_cast<const uint8_t*>(ctx->work);
     }
-    FxGeom g{ rows, cols, p.sz.pad, nframes, 0, (rows + 31) / 32 };
+    const int nkb = p.fx->nkb, pada = 8 * (nkb - 2), nt = (nkb - 1) / 2;
+    FxGeom g{ rows, cols, p.sz.pad, nframes, 0, (rows + 31) / 32, fx_right_strips(cols, pada) };
     g.aligned = ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 3) == 0) ? 1 : 0;
     if (!g.aligned) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: frame pointers must be 4-byte aligned");
-    const int nkb = p.fx->nkb, pada = 8 * (nkb - 2), nt = (nkb - 1) / 2;
     const int qrows = 32 * (g.ntiles + nt), qpitch = (3 * cols + 31) & ~31;
+    {   // the edge chunks' windows
+        const int win = kFxChunk + 2 * pada, nstrips = 1 + g.nright, chunks = (cols + kFxChunk - 1) / kFxChunk;
+        const size_t bytes = static_cast<size_t>(nframes) * nstrips * rows * win * 3 + 64;
+        if (ctx->fx_strips_bytes < bytes) {
+            if (ctx->fx_strips) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->fx_strips)); ctx->fx_strips = nullptr; ctx->fx_strips_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->fx_strips), bytes));
+            ctx->fx_strips_bytes = bytes;
+        }
+        TimedLaunch t(ctx, 1, 0);
+        hipLaunchKernelGGL(fx_edge_strips, dim3((rows * (win / 4) + 255) / 256, nstrips, nframes), dim3(256), 0, ctx->stream, d_src, ctx->fx_strips, rows, cols, pada, chunks,
+                           g.nright);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     float *qrow = nullptr, *qcol = nullptr;
     if (p.mx_quirk) {
-        // scratch per frame: srow_part int [batches][rows][3]; cpart int [bands][3 cols]; then floats: qrow [3][qrows], qcol [qpitch]
+        // scratch per frame: ints: srow_part [batches][rows][3], cpart [bands][3 cols], ccol [3 cols]; 64-bit: zpart [bands][batches][3];
+        // floats: qrow [3][qrows], qcol [qpitch]
         const int nbands = (rows + kFxSumRows - 1) / kFxSumRows, nbatches = (cols / 4 + 255) / 256;
-        const size_t n_srow = static_cast<size_t>(nbatches) * rows * 3, n_cpart = static_cast<size_t>(nbands) * 3 * cols;
-        const size_t sums_bytes = (n_srow + n_cpart) * sizeof(int) * nframes + 64;
+        const size_t n_srow = static_cast<size_t>(nbatches) * rows * 3, n_cpart = static_cast<size_t>(nbands) * 3 * cols, n_ccol = static_cast<size_t>(3) * cols,
+                     n_z = static_cast<size_t>(nbands) * nbatches * 3;
+        auto up4 = [](size_t v) { return (v + 3) & ~static_cast<size_t>(3); };
+        const size_t sums_bytes = (up4(n_srow * nframes) + up4(n_cpart * nframes) + up4(n_ccol * nframes)) * sizeof(int) + (n_z + 3) * nframes * sizeof(long long) + 64;
         const size_t terms_bytes = (static_cast<size_t>(3) * qrows + qpitch) * sizeof(float) * nframes + 64;
         if (ctx->mx_sums_bytes < sums_bytes) {
             if (ctx->mx_sums) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->mx_sums)); ctx->mx_sums = nullptr; ctx->mx_sums_bytes = 0; }
@@ -1526,20 +1546,44 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
             ctx->mx_terms_bytes = terms_bytes;
         }
         int* srow = ctx->mx_sums;
-        int* cpart = srow + ((n_srow * nframes + 3) & ~static_cast<size_t>(3));       // 16-byte aligned: int4 stores
+        int* cpart = srow + up4(n_srow * nframes);                                      // 16-byte aligned: int4 stores
+        int* ccol = cpart + up4(n_cpart * nframes);
+        long long* zpart = reinterpret_cast<long long*>(ccol + up4(n_ccol * nframes));
+        double* zsum = reinterpret_cast<double*>(zpart + n_z * nframes);
         qrow = ctx->mx_terms;
         qcol = qrow + static_cast<size_t>(3) * qrows * nframes;
         { TimedLaunch t(ctx, 1, nframes);
-          hipLaunchKernelGGL(fx_altsums, dim3(nbands, nbatches, nframes), dim3(256), 0, ctx->stream, d_src, srow, cpart, rows, cols, p.sz.pad, nbands, nbatches);
+          hipLaunchKernelGGL(fx_altsums, dim3(nbands, nbatches, nframes), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, rows, cols, p.sz.pad, nbands, nbatches);
           HIP_TRY(ctx, hipGetLastError());
-          const int nrb = (qrows + 255) / 256, ncb = (qpitch + 255) / 256;
-          const size_t lds = static_cast<size_t>(3) * (256 / 3 + 2 + 2 * p.sz.pad + 2) * sizeof(int);
-          hipLaunchKernelGGL(fx_quirk_terms, dim3(nrb + ncb, nframes), dim3(256), lds, ctx->stream, srow, cpart, p.mxt->taps_row, qrow, qcol, rows, cols, p.sz.pad, pada,
-                             qrows, qpitch, nbands, nbatches, nrb, p.mxt->dr, p.mxt->dc);
+          const int nrb = (qrows + 255) / 256, nvb = (3 * cols + 255) / 256, ncb = (qpitch + 255) / 256;
+          hipLaunchKernelGGL(fx_quirk_reduce, dim3(nrb + nvb + 1, nframes), dim3(256), 0, ctx->stream, srow, cpart, zpart, qrow, ccol, zsum, rows, cols, p.sz.pad, pada,
+                             qrows, nbands, nbatches, nrb, nvb, p.mxt->dr);
+          HIP_TRY(ctx, hipGetLastError());
+          const int tileints = 3 * (256 / 3 + 2 + 2 * p.sz.pad + 2);
+          const size_t lds = static_cast<size_t>(tileints) * sizeof(int) + static_cast<size_t>(2 * p.sz.pad + 1) * sizeof(float);
+          hipLaunchKernelGGL(fx_quirk_cols, dim3(ncb, nframes), dim3(256), lds, ctx->stream, ccol, zsum, p.mxt->taps_row, qcol, cols, p.sz.pad, qpitch, tileints, p.mxt->dr,
+                             p.mxt->dc);
           HIP_TRY(ctx, hipGetLastError()); }
     }
+    // diagnostic (timing-only -DFX_STAMPS builds of the kernel write here; see tools/fx_variants.sh): cycles per phase kind
+    unsigned long long* stamps = nullptr;
+    if (!p.mx_quirk && std::getenv("BLUR_FX_STAMPS")) {
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&stamps), 64));
+        HIP_TRY(ctx, hipMemset(stamps, 0, 64));
+        qcol = reinterpret_cast<float*>(stamps);
+    }
     { TimedLaunch t(ctx, 0, nframes);
-      HIP_TRY(ctx, p.fx->blur_u8(ctx->stream, d_src, d_dst, p.mxt->frags_row, g, ctx->num_cus, qrow, qcol, qpitch)); }
+      HIP_TRY(ctx, p.fx->blur_u8(ctx->stream, d_src, d_dst, p.mxt->frags_row, g, ctx->num_cus, qrow, qcol, qpitch, ctx->fx_strips)); }
+    if (stamps) {
+        unsigned long long h[8];
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        HIP_TRY(ctx, hipMemcpy(h, stamps, 64, hipMemcpyDeviceToHost));
+        HIP_TRY(ctx, hipFree(stamps));
+        if (h[7]) {
+            std::fprintf(stderr, "fx stamps: steps %llu, cycles per step: A0 %.0f B0 %.0f A1 %.0f B1 %.0f A2 %.0f B2 %.0f, whole task %.0f per step\n", h[7], h[0] / double(h[7]),
+                         h[1] / double(h[7]), h[2] / double(h[7]), h[3] / double(h[7]), h[4] / double(h[7]), h[5] / double(h[7]), h[6] / double(h[7]));
+        }
+    }
     return BLUR_OK;
 }
 

@@ -30,11 +30,14 @@
 #pragma once
 #include "mx_kernels.hpp"
 
+#if !defined(FX_NO_SGB) && !defined(FX_SGB)
+#define FX_SGB 1     // ask the scheduler for the interleaved order of each phase (sched_group_barrier)
+#endif
 #ifndef FX_SGB_A
-#define FX_SGB_A 6
+#define FX_SGB_A 5
 #endif
 #ifndef FX_SGB_B
-#define FX_SGB_B 5
+#define FX_SGB_B 6
 #endif
 
 namespace blur_amd {
@@ -44,6 +47,7 @@ struct FxGeom {
     int nframes;
     int aligned;      // 1: cols % 4 == 0 and frame pointers 4-byte aligned: 12-byte pixel groups are three aligned dwords
     int ntiles;       // output tiles of 32 rows per frame
+    int nright;       // chunks at the right edge that read their window from a strip (the chunk at the left edge always does)
 };
 
 constexpr int kFxChunk = 128;     // pixel columns per workgroup
@@ -53,8 +57,8 @@ template <int NKB> struct FxCfg {
     static constexpr int PW = mx_row_pitch(NKB);                     // halfs per LDS row of the window
     static constexpr int NT = (NKB - 1) / 2;                          // live accumulator tiles per channel = steps per unrolled round
     static constexpr int BUF = 3 * 32 * PW * 2;                       // bytes of one window buffer
-    static constexpr int QOFF = 2 * BUF;                              // qrow stage: [2][3][32] floats
-    static constexpr int LDS = QOFF + 2 * 96 * 4;
+    static constexpr int QOFF = 2 * BUF;                              // qrow stage: [2 buffers][x even, odd: +q, -q][3][32] floats
+    static constexpr int LDS = QOFF + 2 * 2 * 96 * 4;
 };
 
 // x as binary16: the byte in the low half of a binary16 is the SUBNORMAL x * 2^-24 -- the matrix cores take subnormal
@@ -103,7 +107,7 @@ __device__ __forceinline__ uint32_t fx_quad_transpose(uint32_t p, uint32_t sel1,
 template <int NKB, bool QUIRK>
 __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, FxGeom g,
                                                      int chunks, int tps, int nseg, int ntasks, const float* __restrict__ qrow, const float* __restrict__ qcol,
-                                                     int qpitch)
+                                                     int qpitch, const uint8_t* __restrict__ strips)
 {
     using C = FxCfg<NKB>;
     constexpr int PADA = C::PADA, PW = C::PW, NT = C::NT, PER = C::PER;
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     const int Q = m >> 2, q = m & 3;
     const int xpix = x0 + 32 * wave + 4 * Q;                       // first of the lane's 4 pixels after the transposes
     const bool in_cols = xpix < g.cols;
-    float cpos[3], cneg[3], sgnx = 0.f;
+    float cpos[3], cneg[3];
     {
         const int x = x0 + 32 * wave + m;
 #pragma unroll
@@ -146,7 +150,6 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
             cpos[c] = 0.5f + qc;
             cneg[c] = 0.5f - qc;
         }
-        sgnx = (x & 1) ? -1.f : 1.f;
     }
     const int qrows = 32 * (g.ntiles + NT);
 
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #pragma unroll
         for (int k = 0; k < NT; ++k) acc[c][k] = zero;
     mx_float16 arow = zero;             // the row pass's accumulator
-    uint32_t hl[2][2][8];               // hand-off: [buffer][hi, lo][packed row pairs], block b = entries 4 b .. 4 b + 3
+    uint32_t hl[2][8];                  // hand-off: [hi, lo][packed row pairs], block b = entries 4 b .. 4 b + 3
     uint32_t rr[3][4];                  // finished tile, per channel and row group: 4 pixels of one row (after the quad transpose)
 
     // step s handles rows 32 s .. 32 s + 31 of V (row re of V = image row refl(re - PADA)) and emits tile s - NT
@@ -165,169 +168,227 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     FxRaw<NKB> raw;
     float qraw = 0.f;
     // staging in three chunks of three 12-byte groups: commit chunk j of window s, then refill the registers with window s + 1
-    // Reflect-101 along the rows (Source.cpp:525-529) is done by the loads: the image width is a multiple of 4, so a 12-byte group
-    // of the window lies inside the image or outside it, and a group outside is the pixel-reversed copy of a group inside, 3 bytes
-    // (left) or 1 byte (right) off the dword grid -- gfx950 loads it unaligned; the commit reverses its pixels (other selectors of
-    // the same v_perm_b32).  Only the chunks at the two edges (uniform per workgroup) run that code.  The frame is a buffer
-    // resource: mirrored groups beyond the reach of the taps (tiny images) may fall outside it and read as zero.
-    const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, static_cast<uint32_t>(g.rows) * g.cols * 3u, kMxRsrcWord3);
-    const bool edge = x0 - PADA < 0 || x0 + kFxChunk + PADA > g.cols;      // uniform
-    auto group_x = [&](int k, bool& mir) __attribute__((always_inline)) {  // first source pixel of group k of this thread
-        const int X = x0 - PADA + 4 * ((tid & 7) + 8 * k);
-        mir = X < 0 || X >= g.cols;
-        return X < 0 ? -X - 3 : (X >= g.cols ? 2 * g.cols - 5 - X : X);
-    };
+    // Reflect-101 along the rows (Source.cpp:525-529) never shows in this kernel: a chunk whose window reaches over the image's left
+    // or right edge reads it from a STRIP -- a copy of its 128 + 2 PADA window columns with the mirrored pixels in place, written by
+    // fx_edge_strips before the launch (1 + nright strips per frame) -- and every other chunk's window lies inside the image.  So a
+    // window row is 17 x 4 twelve-byte groups at base + row * pitch for every workgroup; the source is a buffer resource (groups
+    // past the end of the last row read as zero; they only meet zero taps).
+    const int sidx = xc == 0 ? 0 : (xc >= chunks - g.nright ? 1 + xc - (chunks - g.nright) : -1);      // uniform
+    const uint32_t pitch = sidx >= 0 ? 3u * C::WIN : 3u * static_cast<uint32_t>(g.cols);
+    const uint8_t* wbase = sidx >= 0 ? strips + (static_cast<size_t>(f) * (1 + g.nright) + sidx) * g.rows * (3 * C::WIN) : img + 3 * (x0 - PADA);
+    const uint32_t wbytes = sidx >= 0 ? static_cast<uint32_t>(g.rows) * 3u * C::WIN : (static_cast<uint32_t>(g.rows) * g.cols - static_cast<uint32_t>(x0 - PADA)) * 3u;
+    const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wbase), 0, wbytes, kMxRsrcWord3);
     auto issue_chunk = [&](int s, int j) __attribute__((always_inline)) {
         const int row = tid >> 3, g0 = tid & 7;
+#ifdef FX_ABL_NOLOAD
+        if (s >= 0) return;
+#endif
         const int r = mx_refl(32 * s - PADA + row, g.rows);
+        const uint32_t off = static_cast<uint32_t>(r) * pitch + 12u * g0;
         typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-        if (!edge) {
-            const uint32_t off = (static_cast<uint32_t>(r) * g.cols + static_cast<uint32_t>(x0 - PADA + 4 * g0)) * 3u;
 #pragma unroll
-            for (int k = 3 * j; k < 3 * j + 3 && k < PER; ++k) {
-                const bool in = (C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8;
-                const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rimg, in ? off + 96u * k : off, 0, 0);
-                raw.d[k][0] = t[0]; raw.d[k][1] = t[1]; raw.d[k][2] = t[2];
-            }
-        } else {
-            const uint32_t rowoff = static_cast<uint32_t>(r) * g.cols * 3u;
-#pragma unroll
-            for (int k = 3 * j; k < 3 * j + 3 && k < PER; ++k) {
-                bool mir;
-                const int xs = group_x(k, mir);
-                const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rimg, rowoff + 3u * static_cast<uint32_t>(xs), 0, 0);
-                raw.d[k][0] = t[0]; raw.d[k][1] = t[1]; raw.d[k][2] = t[2];
-            }
+        for (int k = 3 * j; k < 3 * j + 3 && k < PER; ++k) {
+            const bool in = (C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8;
+            const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rimg, in ? off + 96u * k : off, 0, 0);
+            raw.d[k][0] = t[0]; raw.d[k][1] = t[1]; raw.d[k][2] = t[2];
         }
         if (QUIRK && j == 0 && tid < 96) {
             const int c = tid >> 5, re = 32 * s + (tid & 31);
             qraw = qrow[(static_cast<size_t>(f) * 3 + c) * qrows + min(re, qrows - 1)];
         }
     };
-    auto commit_chunk = [&](int buf, int j) __attribute__((always_inline)) {
+    // one (group k, channel c) of the window: two v_perm_b32 (deinterleave + the low byte of a binary16 each) and one ds_write_b64
+    auto commit_item = [&](int buf, int k, int c) __attribute__((always_inline)) {
+#ifdef FX_ABL_NOCOMMIT
+        if (buf >= 0) return;
+#endif
         const int row = tid >> 3, g0 = tid & 7;
-        _Float16* base = reinterpret_cast<_Float16*>(fx_lds + buf * C::BUF) + row * PW + 4 * g0;
-#pragma unroll
-        for (int k = 3 * j; k < 3 * j + 3 && k < PER; ++k) {
-            if ((C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8) {
-                bool mir = false;
-                if (edge) (void)group_x(k, mir);
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    // window pixels (0, 1) and (2, 3) of the group: source bytes (c, 3 + c) and (6 + c, 9 + c); mirrored: (9 + c, 6 + c) and (3 + c, c)
-                    auto pick = [&](int B0, int B1) __attribute__((always_inline)) {
-                        const int da = B1 >> 2, db = B0 >> 2;
-                        const uint32_t sel = fx_sel1(B0, da, db) | (0x0cu << 8) | (fx_sel1(B1, da, db) << 16) | (0x0cu << 24);
-                        return __builtin_amdgcn_perm(raw.d[k][da], raw.d[k][db], sel);
-                    };
-                    uint2 wd;
-                    wd.x = pick(c, 3 + c);
-                    wd.y = pick(6 + c, 9 + c);
-                    if (edge) {
-                        const uint32_t mx_ = pick(9 + c, 6 + c), my_ = pick(3 + c, c);
-                        wd.x = mir ? mx_ : wd.x;
-                        wd.y = mir ? my_ : wd.y;
-                    }
-                    *reinterpret_cast<uint2*>(base + c * 32 * PW + 32 * k) = wd;
-                }
-            }
+        if (k >= PER) return;
+        if ((C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8) {
+            _Float16* base = reinterpret_cast<_Float16*>(fx_lds + buf * C::BUF) + row * PW + 4 * g0;
+            // window pixels (0, 1) and (2, 3) of the group: bytes (c, 3 + c) and (6 + c, 9 + c)
+            auto pick = [&](int B0, int B1) __attribute__((always_inline)) {
+                const int da = B1 >> 2, db = B0 >> 2;
+                const uint32_t sel = fx_sel1(B0, da, db) | (0x0cu << 8) | (fx_sel1(B1, da, db) << 16) | (0x0cu << 24);
+                return __builtin_amdgcn_perm(raw.d[k][da], raw.d[k][db], sel);
+            };
+            uint2 wd;
+#ifdef FX_ABL_NOPERM
+            wd.x = raw.d[k][c]; wd.y = raw.d[k][(c + 1) % 3];
+#else
+            wd.x = pick(c, 3 + c);
+            wd.y = pick(6 + c, 9 + c);
+#endif
+#ifdef FX_ABL_NODSWRITE
+            asm volatile("" ::"v"(wd.x), "v"(wd.y));
+#else
+            *reinterpret_cast<uint2*>(base + c * 32 * PW + 32 * k) = wd;
+#endif
         }
-        if (QUIRK && j == 0 && tid < 96) reinterpret_cast<float*>(fx_lds + C::QOFF)[buf * 96 + tid] = qraw;
+    };
+    auto commit_q = [&](int buf) __attribute__((always_inline)) {
+        if (QUIRK && tid < 96) {
+            float* qs = reinterpret_cast<float*>(fx_lds + C::QOFF) + buf * 192 + tid;
+            qs[0] = qraw;            // the term enters as qrow (-1)^x: lanes of even x read this copy,
+            qs[96] = -qraw;          // lanes of odd x this one
+        }
+    };
+    auto commit_chunk = [&](int buf, int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) commit_item(buf, 3 * j + i / 3, i % 3);
+        if (j == 0) commit_q(buf);
     };
     // R: 32 rows x 32 pixels of channel c of the window in buffer `buf` -> arow
-    auto rowpass = [&](int buf, int c) __attribute__((always_inline)) {
+    // `beside(kb)` runs between the products of window block kb and kb + 1: the phase's vector work is handed out in slices, and a
+    // scheduling fence after every block keeps the slices where they are (a window read is in flight for three blocks)
+    auto rowpass = [&](int buf, int c, auto beside) __attribute__((always_inline)) {
         const _Float16* base = reinterpret_cast<const _Float16*>(fx_lds + buf * C::BUF) + (c * 32 + m) * PW + wave * 32 + 8 * h;
         mx_float16 a = zero;
+        mx_half8 x[4];
+#pragma unroll
+#ifdef FX_ABL_NOXREAD
+        for (int kb = 0; kb < 4; ++kb) x[kb] = th[kb];
+#else
+        for (int kb = 0; kb < 3 && kb < NKB; ++kb) x[kb] = *reinterpret_cast<const mx_half8*>(base + 16 * kb);
+#endif
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
-            const mx_half8 x = *reinterpret_cast<const mx_half8*>(base + 16 * kb);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, th[kb], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x, tl[kb], a, 0, 0, 0);
+#ifndef FX_ABL_NOXREAD
+            if (kb + 3 < NKB) x[(kb + 3) & 3] = *reinterpret_cast<const mx_half8*>(base + 16 * (kb + 3));
+#endif
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[kb & 3], th[kb], a, 0, 0, 0);
+            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[kb & 3], tl[kb], a, 0, 0, 0);
+            asm volatile("" : "+a"(a));          // pins the two products between this block's fences (they have no other side effect)
+            beside(kb);
+#ifdef FX_SGB
+            // inside the block: the slice's vector work after each product, not behind both
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, FX_SGB_A, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, FX_SGB_A, 0);
+#endif
+#ifndef FX_NOSB
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         arow = a;
     };
-    // S: arow -> scale (+ quirk), split into hi + lo, exchange with lane ^ 32 -> hl[hb]
-    auto split = [&](int hb, int buf, int c) __attribute__((always_inline)) {
-        float v[16];
-        if (QUIRK) {
-            const float* qs4 = reinterpret_cast<const float*>(fx_lds + C::QOFF) + buf * 96 + c * 32 + 4 * h;
+    // S: arow -> scale (+ quirk), split into hi + lo, exchange with lane ^ 32 -> hl; in eight pieces (two halves of the 32 rows x
+    // {read + scale -> sv, convert two row pairs, convert the other two, exchange}).  Phase B(n) runs the two read pieces of product n + 1 (the row accumulator is
+    // free again before R(n + 2) starts), phase A(n + 1) the other four: B is the phase whose vector work fills its matrix time
+    float sv[16];
+    auto split_piece = [&](int buf, int c, int piece) __attribute__((always_inline)) {
+        const int hf = piece / 4, sub = piece % 4;       // sub: 0 read + scale, 1 / 2 convert row pairs 0, 1 / 2, 3, 3 exchange
+        uint32_t (&hp)[8] = hl[0];
+        uint32_t (&lp)[8] = hl[1];
+#ifdef FX_ABL_NOSPLIT
+        if (sub == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4 t4 = *reinterpret_cast<const float4*>(qs4 + 8 * k);
-                v[4 * k] = __builtin_fmaf(arow[4 * k], kFxRowUnscale, t4.x * sgnx);
-                v[4 * k + 1] = __builtin_fmaf(arow[4 * k + 1], kFxRowUnscale, t4.y * sgnx);
-                v[4 * k + 2] = __builtin_fmaf(arow[4 * k + 2], kFxRowUnscale, t4.z * sgnx);
-                v[4 * k + 3] = __builtin_fmaf(arow[4 * k + 3], kFxRowUnscale, t4.w * sgnx);
+            for (int k = 0; k < 4; ++k) { hp[4 * hf + k] = __builtin_bit_cast(uint32_t, arow[8 * hf + k]); lp[4 * hf + k] = __builtin_bit_cast(uint32_t, arow[8 * hf + 4 + k]); }
+        }
+        return;
+#endif
+        if (sub == 0) {
+            if (QUIRK) {
+                const float* qs4 = reinterpret_cast<const float*>(fx_lds + C::QOFF) + buf * 192 + (m & 1) * 96 + c * 32 + 4 * h;
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const float4 t4 = *reinterpret_cast<const float4*>(qs4 + 8 * (2 * hf + k));
+                    sv[8 * hf + 4 * k] = __builtin_fmaf(arow[8 * hf + 4 * k], kFxRowUnscale, t4.x);
+                    sv[8 * hf + 4 * k + 1] = __builtin_fmaf(arow[8 * hf + 4 * k + 1], kFxRowUnscale, t4.y);
+                    sv[8 * hf + 4 * k + 2] = __builtin_fmaf(arow[8 * hf + 4 * k + 2], kFxRowUnscale, t4.z);
+                    sv[8 * hf + 4 * k + 3] = __builtin_fmaf(arow[8 * hf + 4 * k + 3], kFxRowUnscale, t4.w);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) sv[8 * hf + k] = arow[8 * hf + k] * kFxRowUnscale;
+            }
+        } else if (sub == 1 || sub == 2) {
+#pragma unroll
+            for (int k = 2 * (sub - 1); k < 2 * sub; ++k) {
+                typedef float f2 __attribute__((ext_vector_type(2)));
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const f2 vv = { sv[8 * hf + 2 * k], sv[8 * hf + 2 * k + 1] };
+                hp[4 * hf + k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(vv, h2));
+                float r0, r1;
+                mx_remainder(hp[4 * hf + k], vv[0], vv[1], r0, r1);
+                const f2 rem = { r0, r1 };
+                lp[4 * hf + k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, h2));
             }
         } else {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) v[k] = arow[k] * kFxRowUnscale;
+            // regs (0..3, 4..7) of the half = rows (0..3, 8..11) + 4 h of its 16-row block -> the lane wants rows 8 h .. 8 h + 7
+#ifndef FX_ABL_NOSWAP
+            fx_swap4(hp[4 * hf], hp[4 * hf + 2], hp[4 * hf + 1], hp[4 * hf + 3], lp[4 * hf], lp[4 * hf + 2], lp[4 * hf + 1], lp[4 * hf + 3]);
+#endif
         }
-        uint32_t (&hp)[8] = hl[hb][0];
-        uint32_t (&lp)[8] = hl[hb][1];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            typedef float f2 __attribute__((ext_vector_type(2)));
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            const f2 vv = { v[2 * k], v[2 * k + 1] };
-            hp[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(vv, h2));
-            float r0, r1;
-            mx_remainder(hp[k], vv[0], vv[1], r0, r1);
-            const f2 rem = { r0, r1 };
-            lp[k] = __builtin_bit_cast(uint32_t, __builtin_convertvector(rem, h2));
-        }
-        // regs (0..3, 4..7) = rows (0..3, 8..11) + 4 h -> block 0 wants rows 8 h .. 8 h + 7; same for regs 8..15 and block 1
-        fx_swap4(hp[0], hp[2], hp[1], hp[3], lp[0], lp[2], lp[1], lp[3]);
-        fx_swap4(hp[4], hp[6], hp[5], hp[7], lp[4], lp[6], lp[5], lp[7]);
     };
-    // C + E: column pass of (step slot qs, channel c) from hl[hb]; the finished tile's bytes -> rr[c]
-    auto colpass = [&](int hb, int c, int qs) __attribute__((always_inline)) {
+    // E: one row group (4 rows) of the finished tile -> bytes, 4 x 4 transposed inside the lane quads -> rr[c][gq]
+    mx_float16 tfin = zero;
+    auto emit_piece = [&](int c, int gq) __attribute__((always_inline)) {
+#ifdef FX_ABL_NOEMIT
+        rr[c][gq] = __builtin_bit_cast(uint32_t, tfin[5 * gq]);
+        return;
+#endif
+        float fv[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int reg = 4 * gq + k;
+            fv[k] = __builtin_fmaf(tfin[reg], kMxUnscale, (reg & 1) ? cneg[c] : cpos[c]);
+        }
+        // (uint8_t)(v + 0.5f) of the reference (Utils.hpp:189,204-206): truncate, keep the low byte (values past 255.5, which only
+        // the quirk's terms reach, wrap as on x86) -- the conversion writes its byte of the packed dword itself (SDWA)
+        uint32_t pk = static_cast<uint32_t>(static_cast<int>(fv[0]));
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(pk) : "v"(fv[1]));
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_2 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(pk) : "v"(fv[2]));
+        asm("v_cvt_i32_f32_sdwa %0, %1 dst_sel:BYTE_3 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(pk) : "v"(fv[3]));
+        rr[c][gq] = fx_quad_transpose(pk, sel1, sel2);
+    };
+    // C (+ S of the next product, + E): column pass of (step slot qs, channel c) from hl.  NKB triples of products: first the
+    // tile that FINISHES with block 0 of this step (its window block NKB - 1), then blocks 2 .. NKB - 2 of the tiles in flight,
+    // last blocks 0 and 1 of the tile that STARTS -- into the finished tile's registers, which E has read by then.  `beside(it)`
+    // runs after triple it; a scheduling fence after every triple keeps the slices where they are.
+    auto colpass = [&](int c, int qs, auto beside) __attribute__((always_inline)) {
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
         mx_half8 v1[2], v2[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-            const u4 w1 = { hl[hb][0][4 * b], hl[hb][0][4 * b + 1], hl[hb][0][4 * b + 2], hl[hb][0][4 * b + 3] };
-            const u4 w2 = { hl[hb][1][4 * b], hl[hb][1][4 * b + 1], hl[hb][1][4 * b + 2], hl[hb][1][4 * b + 3] };
+            const u4 w1 = { hl[0][4 * b], hl[0][4 * b + 1], hl[0][4 * b + 2], hl[0][4 * b + 3] };
+            const u4 w2 = { hl[1][4 * b], hl[1][4 * b + 1], hl[1][4 * b + 2], hl[1][4 * b + 3] };
             v1[b] = __builtin_bit_cast(mx_half8, w1);
             v2[b] = __builtin_bit_cast(mx_half8, w2);
         }
-        {   // the tile that finishes with block 0 of this step (window block NKB - 1)
-            constexpr int d = NKB - 1;
-            const int slot = qs % NT;
-            mx_float16 t = acc[c][slot];
-            const mx_half8 fh = th[d], fl = tl[d];
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, v1[0], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, v1[0], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, v2[0], t, 0, 0, 0);
 #pragma unroll
-            for (int gq = 0; gq < 4; ++gq) {
-                uint32_t by[4];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int reg = 4 * gq + k;
-                    by[k] = static_cast<uint32_t>(static_cast<int>(__builtin_fmaf(t[reg], kMxUnscale, (reg & 1) ? cneg[c] : cpos[c])));
-                }
-                const uint32_t t01 = __builtin_amdgcn_perm(by[1], by[0], 0x0c0c0400u), t23 = __builtin_amdgcn_perm(by[3], by[2], 0x04000c0cu);
-                rr[c][gq] = fx_quad_transpose(t01 | t23, sel1, sel2);
-            }
-        }
-        // window blocks 2 .. NKB - 2 of the tiles in flight, then blocks 0 and 1 of the tile that starts (into the finished tile's
-        // registers)
-#pragma unroll
-        for (int dd = 2; dd < NKB + 1; ++dd) {
-            const int d = dd >= NKB - 1 ? dd - (NKB - 1) : dd, b = d & 1, a2 = d >> 1, slot = (qs - a2 + 2 * NT) % NT;
+        for (int it = 0; it < NKB; ++it) {
+            const int d = it == 0 ? NKB - 1 : (it >= NKB - 2 ? it - (NKB - 2) : it + 1);
+            const int b = d & 1, a2 = d >> 1, slot = (qs - a2 + 2 * NT) % NT;
             mx_float16 t = d == 0 ? zero : acc[c][slot];
-            const mx_half8 fh = th[d], fl = tl[d];
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, v1[b], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fl, v1[b], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(fh, v2[b], t, 0, 0, 0);
-            acc[c][slot] = t;
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v1[b], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[d], v1[b], t, 0, 0, 0);
+            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v2[b], t, 0, 0, 0);
+            asm volatile("" : "+a"(t));          // pins the three products between this triple's fences
+            if (it == 0) tfin = t; else acc[c][slot] = t;
+            beside(it);
+#ifdef FX_SGB
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, FX_SGB_B, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, FX_SGB_B, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, FX_SGB_B, 0);
+#endif
+#ifndef FX_NOSB
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
     };
-    // F: the finished tile (rr) -> 12 interleaved bytes per lane and row group -> memory
-    auto store_tile = [&](int tile) __attribute__((always_inline)) {
-#pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
+    // F: the finished tile (rr) -> 12 interleaved bytes per lane and row group -> memory.  Buffer stores: rows past the image fall
+    // outside the resource and are dropped by its bounds check; lanes whose quad lies right of the image, and tiles that do not
+    // exist (run-in of a segment), get an offset outside it -- no branch.
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out, 0, static_cast<uint32_t>(g.rows) * g.cols * 3u, kMxRsrcWord3);
+    const uint32_t lane_out = (static_cast<uint32_t>(4 * h + q) * g.cols + static_cast<uint32_t>(xpix)) * 3u;
+    auto store_group = [&](int tile, bool valid, int gq) __attribute__((always_inline)) {
+        {
             const uint32_t r0 = rr[0][gq], r1 = rr[1][gq], r2 = rr[2][gq];
             // lane q of the quad holds row q: r_c = channel c of pixels 0..3 -> 12 interleaved bytes
             const uint32_t X = __builtin_amdgcn_perm(r1, r0, 0x05010400u);      // [r0.0, r1.0, r0.1, r1.1]
@@ -336,13 +397,20 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
             const uint32_t Z = __builtin_amdgcn_perm(r2, X, 0x0c0c0503u);       // [X3, r2.1, 0, 0]
             const uint32_t w1 = __builtin_amdgcn_perm(Y, Z, 0x05040100u);       // [Z0, Z1, Y0, Y1]
             const uint32_t w2 = __builtin_amdgcn_perm(r2, Y, 0x07030206u);      // [r2.2, Y2, Y3, r2.3]
-            const int row = 32 * tile + 8 * gq + 4 * h + q;
-            if (row < g.rows && in_cols) {                              // (cols is a multiple of 4: a quad is inside or outside)
-                typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-                const u3 w = { w0, w1, w2 };
-                *reinterpret_cast<u3*>(out + (static_cast<size_t>(row) * g.cols + xpix) * 3) = w;
-            }
+            typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+            const u3 w = { w0, w1, w2 };
+            const uint32_t rowoff = static_cast<uint32_t>(32 * tile + 8 * gq) * g.cols * 3u;        // uniform
+#ifdef FX_ABL_NOSTORE
+            const bool ok = false;
+#else
+            const bool ok = valid && in_cols && 32 * tile + 8 * gq + 4 * h + q < g.rows;
+#endif
+            __builtin_amdgcn_raw_buffer_store_b96(w, rout, ok ? lane_out + rowoff : 0xfffffff0u, 0, 0);
         }
+    };
+    auto store_tile = [&](int tile, bool valid) __attribute__((always_inline)) {
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) store_group(tile, valid, gq);
     };
 
     // prologue: window s0 and chunk 0 of window s0 + 1 in LDS; in the registers chunks 1, 2 of window s0 + 1 and chunk 0 of
@@ -357,9 +425,17 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     issue_chunk(s0 + 1, 2);
     issue_chunk(s0 + 2, 0);
     __syncthreads();
-    rowpass(0, 0);
-    split(0, 0, 0);
+    rowpass(0, 0, [](int) {});
+    split_piece(0, 0, 0);
+    split_piece(0, 0, 4);
 
+#ifdef FX_STAMPS
+    // timing-only build: cycles (s_memtime) per phase kind, summed over the steps, by wave 0 of workgroup 0 -> the buffer passed as qcol
+    unsigned long long st_acc[6] = { 0, 0, 0, 0, 0, 0 }, st_prev = __builtin_amdgcn_s_memtime(), st_begin = st_prev;
+#define FX_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; }
+#else
+#define FX_STAMP(i)
+#endif
     for (int sb = s0; sb < s1; sb += NT) {
 #pragma unroll
         for (int qs = 0; qs < NT; ++qs) {
@@ -368,54 +444,83 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
             const int cur = (s - s0) & 1;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const int hb = (3 * qs + c) & 1;                           // hand-off buffer (static: see the copy after the round)
                 // ---- phase A: the next product's row pass; staging of window s + 2 (chunks in A(s,2), A(s+1,0), A(s+1,1)); stores
+#ifndef FX_ABL_NOBARRIER
                 if (c == 2) __syncthreads();                               // window s + 1 complete, window s no longer read
+#endif
 #ifndef FX_NOSB
                 __builtin_amdgcn_sched_barrier(0);
 #endif
-                if (c == 2) rowpass(cur ^ 1, 0); else rowpass(cur, c + 1);
-                if (c == 2) { commit_chunk(cur, 0); issue_chunk(s + 3, 0); }
-                else if (c == 0) { commit_chunk(cur ^ 1, 1); issue_chunk(s + 2, 1); }
-                else { commit_chunk(cur ^ 1, 2); issue_chunk(s + 2, 2); }
-                if (c == 0 && s - 1 - NT >= tile0 && s > s0) store_tile(s - 1 - NT);
-#ifdef FX_SGB
-                // the order the scheduler is asked for: window reads three blocks ahead, staging spread between the products
-                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                {
+                    // staging chunk of this phase: (c == 2) chunk 0 of window s + 2 -> buffer cur, then the loads of window s + 3;
+                    // (c == 0, 1) chunk c + 1 of window s + 1 -> buffer cur ^ 1, then the loads of window s + 2
+                    const int jc = c == 2 ? 0 : c + 1, cbuf = c == 2 ? cur : cur ^ 1, snext = c == 2 ? s + 3 : s + 2;
+                    const bool tvalid = s - 1 - NT >= tile0 && s > s0;
+                    // slices beside the NKB window blocks: nine commit items, the finished tile's four row groups (c == 0), the loads
+                    constexpr int NI = NKB >= 11 ? 1 : (NKB >= 6 ? 2 : (NKB >= 4 ? 3 : 5));     // items per slice so that nine fit
+                    auto beside = [&](int kb) __attribute__((always_inline)) {
+                        // the hand-off of the product phase B is about to consume (its row accumulator was read in the previous B)
+                        if (NKB >= 11) {
+                            // at most a dozen vector instructions beside a pair of products: conversions in blocks 0 .. 3, exchanges in 2
+                            // and 4, the nine commit items in 2 .. 10, the finished tile's row groups (c == 0) in 5 .. 8, the loads last
+                            if (kb == 0) split_piece(cur, c, 1);
+                            if (kb == 1) split_piece(cur, c, 2);
+                            if (kb == 2) { split_piece(cur, c, 3); split_piece(cur, c, 5); }
+                            if (kb == 3) split_piece(cur, c, 6);
+                            if (kb == 4) split_piece(cur, c, 7);
+                            if (kb >= 2) commit_item(cbuf, 3 * jc + (kb - 2) / 3, (kb - 2) % 3);
+                            if (c == 0 && kb >= 5 && kb <= 8) store_group(s - 1 - NT, tvalid, kb - 5);
+                            if (kb == NKB - 1) { if (jc == 0) commit_q(cbuf); issue_chunk(snext, jc); }
+                        } else {
+                            if (kb == 0) { split_piece(cur, c, 1); split_piece(cur, c, 2); split_piece(cur, c, 3); split_piece(cur, c, 5); split_piece(cur, c, 6); split_piece(cur, c, 7); }
 #pragma unroll
-                for (int i = 0; i < NKB; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, FX_SGB_A, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                            for (int i = NI * kb; i < NI * kb + NI && i < 9; ++i) commit_item(cbuf, 3 * jc + i / 3, i % 3);
+                            if (kb == NKB - 1) { if (jc == 0) commit_q(cbuf); issue_chunk(snext, jc); }
+                            if (c == 0 && kb == NKB - 1) store_tile(s - 1 - NT, tvalid);
+                        }
+                    };
+                    if (c == 2) rowpass(cur ^ 1, 0, beside); else rowpass(cur, c + 1, beside);
                 }
-#endif
 #ifndef FX_NOSB
                 __builtin_amdgcn_sched_barrier(0);
 #endif
+                FX_STAMP(2 * c)
                 // ---- phase B: this product's column pass; the next product's hand-off; this tile's bytes
-                colpass(hb, c, qs);
-                if (c == 2) split(hb ^ 1, cur ^ 1, 0); else split(hb ^ 1, cur, c + 1);
-#ifdef FX_SGB
-                __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);
+                {
+                    const int nbuf = c == 2 ? cur ^ 1 : cur, nc = c == 2 ? 0 : c + 1;
+                    auto beside = [&](int it) __attribute__((always_inline)) {
+                        if (NKB >= 11) {
+                            // S (read pieces) after triples 1, 2; E: row groups after triples 3 .. 6 (the tile that starts takes the
+                            // finished tile's registers in triple NKB - 2)
+                            if (it == 1) split_piece(nbuf, nc, 0);
+                            if (it == 2) split_piece(nbuf, nc, 4);
+                            if (it >= 3 && it <= 6) emit_piece(c, it - 3);
+                        } else {
+                            if (it == (NKB >= 5 ? 1 : 0)) { split_piece(nbuf, nc, 0); split_piece(nbuf, nc, 4); }
+                            if (it == (NKB >= 5 ? NKB - 3 : 0)) {
 #pragma unroll
-                for (int i = 0; i < 3 * NKB - 3; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x002, FX_SGB_B, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                                for (int gq = 0; gq < 4; ++gq) emit_piece(c, gq);
+                            }
+                        }
+                    };
+                    colpass(c, qs, beside);
                 }
-#endif
 #ifndef FX_NOSB
                 __builtin_amdgcn_sched_barrier(0);
 #endif
+                FX_STAMP(2 * c + 1)
             }
         }
-        // a round is 3 NT products, an odd number: its last hand-off went to buffer 1, the next round starts reading buffer 0
-        if ((3 * NT) & 1) {
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { hl[0][0][k] = hl[1][0][k]; hl[0][1][k] = hl[1][1][k]; }
-        }
     }
-    if (s1 - 1 - NT >= tile0) store_tile(s1 - 1 - NT);
+    store_tile(s1 - 1 - NT, s1 - 1 - NT >= tile0);
+#ifdef FX_STAMPS
+    if (!QUIRK && qcol && blockIdx.x == 0 && tid == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(qcol));
+        for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
+        o[6] = __builtin_amdgcn_s_memtime() - st_begin;
+        o[7] = static_cast<unsigned long long>(s1 - s0);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -425,10 +530,59 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 //     out[r][x] = colconv(V')[r][x] + dc (-1)^(r+pad) Scol(x),  Scol(x) = sum_r wy(r) V'[r][x]
 //                                                                       = rowconv(Ccol)(x) + dr (-1)^(x+pad) Z
 //     Ccol(x) = sum_r wy(r) img[r][x]  (integers; the row convolution and the weighted column sum commute),  Z = sum_r wy(r) Srow(r)
-// fx_altsums reads the image once and leaves Srow and, per band of rows, the partial Ccol; fx_quirk_terms turns them into
+// fx_altsums reads the image once and leaves the parts of Srow, Ccol and Z; fx_quirk_reduce and fx_quirk_cols turn them into
 // qrow[f][c][re] = dr (-1)^pad Srow[refl(re - PADA)][c] and qcol[f][3 x + c] = dc (-1)^pad Scol, which the fused kernel adds
 // as qrow (-1)^x (to V, before the hand-off) and qcol (-1)^r (to the output, before the truncation).
 #ifdef BLUR_FX_QUIRK_KERNELS   // engine.hip only: plain (non-template) kernels must live in one translation unit
+// chunks at the right edge whose window (128 + 2 pada columns from 128 xc - pada) reaches past the image: they read a strip
+inline int fx_right_strips(int cols, int pada)
+{
+    const int chunks = (cols + kFxChunk - 1) / kFxChunk;
+    int n = 0;
+    for (int xc = chunks - 1; xc >= 1 && kFxChunk * xc + kFxChunk + pada > cols; --xc) ++n;
+    return n;
+}
+
+// strips[f][strip][row][p][3], p = 0 .. 128 + 2 pada - 1: pixel refl101(x0 - pada + p) of the row, x0 = 128 xc of the strip's chunk
+// (beyond one reflection, which only zero taps read: whatever the clamped load returns).  A thread moves one group of 4 pixels: the
+// image width is a multiple of 4 and so is x0 - pada, so a group lies inside the image (one aligned 12-byte load) or is the
+// pixel-reversed copy of 4 adjacent image pixels (one unaligned 12-byte load, three v_perm_b32).
+// grid (blocks over rows x win / 4 groups, strips, frames)
+__global__ __launch_bounds__(256) void fx_edge_strips(const uint8_t* __restrict__ src, uint8_t* __restrict__ strips, int rows, int cols, int pada, int chunks, int nright)
+{
+    const int win = kFxChunk + 2 * pada, gpr = win / 4, f = blockIdx.z, sidx = blockIdx.y;
+    const int xc = sidx == 0 ? 0 : chunks - nright + sidx - 1, x0 = kFxChunk * xc;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * gpr) return;
+    const int r = i / gpr, gidx = i - r * gpr;
+    const int X = x0 - pada + 4 * gidx;
+    const bool mir = X < 0 || X >= cols;
+    const int xs = X < 0 ? -X - 3 : (X >= cols ? 2 * cols - 5 - X : X);
+    const uint8_t* line = src + (static_cast<size_t>(f) * rows + r) * cols * 3;
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    u3 o;
+    if (xs >= 0 && xs + 3 < cols) {
+        const u3 d = *reinterpret_cast<const u3*>(line + 3 * xs);
+        o = d;
+        if (mir) {       // pixels 3, 2, 1, 0 of the loaded four: bytes [9 10 11 6] [7 8 3 4] [5 0 1 2]
+            o[0] = __builtin_amdgcn_perm(d[2], d[1], 0x02070605u);
+            o[1] = (d[1] >> 24) | ((d[2] & 0xffu) << 8) | ((d[0] >> 24) << 16) | ((d[1] & 0xffu) << 24);
+            o[2] = __builtin_amdgcn_perm(d[1], d[0], 0x02010005u);
+        }
+    } else {             // reaches past one reflection (tiny images): pixel by pixel
+        uint32_t b[12];
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const uint8_t* px = line + 3 * mx_refl(X + qd, cols);
+            b[3 * qd] = px[0]; b[3 * qd + 1] = px[1]; b[3 * qd + 2] = px[2];
+        }
+        o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+        o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+        o[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+    }
+    *reinterpret_cast<u3*>(strips + ((static_cast<size_t>(f) * (1 + nright) + sidx) * rows + r) * (3 * win) + 12 * gidx) = o;
+}
+
 constexpr int kFxSumRows = 32;          // image rows per band (packed 16-bit column sums: 32 x 3 x 255 < 65536)
 
 // sum over the 16 lanes of a DPP row, valid in every lane of the row
@@ -445,17 +599,17 @@ __device__ __forceinline__ int fx_row16_sum(int v)
 // group (4 pixels) of every row of the band, eight rows of loads in flight; cols % 4 == 0, frames 4-byte aligned.
 //   srow_part[f][batch][r][c]  sum over the batch's pixels of wx(x) img[r][x][c]
 //   cpart[f][band][3 x + c]    sum over the band's rows of wy(r) img[r][x][c]
-__global__ __launch_bounds__(256) void fx_altsums(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, int rows, int cols, int pad,
-                                                  int nbands, int nbatches)
+//   zpart[f][band][batch][c]   sum over the band's rows of wy(r) srow_part[f][batch][r][c]       (the parts of Z)
+__global__ __launch_bounds__(256) void fx_altsums(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
+                                                  int rows, int cols, int pad, int nbands, int nbatches)
 {
-    __shared__ int sred[kFxSumRows][3];
+    __shared__ int sred[kFxSumRows][3][16];        // per row and channel: the 16 row-of-16-lanes sums of the workgroup (no atomics:
+                                                   // the compiler turns a same-address LDS atomic into a serial loop over the lanes)
     const int f = blockIdx.z, batch = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
     const uint8_t* img = src + static_cast<size_t>(f) * rows * cols * 3;
     const int groups = cols / 4, r0 = band * kFxSumRows, r1 = min(r0 + kFxSumRows, rows);
     const int gi = batch * 256 + tid, x = 4 * gi;
     const bool act = gi < groups;
-    if (tid < kFxSumRows * 3) (&sred[0][0])[tid] = 0;
-    __syncthreads();
     const int flip = (pad & 1) ? -1 : 1;
     const bool plain = x > pad && x + 3 < cols - 1 - pad;                 // no pixel of the group is mirrored: weights +-1 by parity
     int wq[4];
@@ -504,7 +658,7 @@ __global__ __launch_bounds__(256) void fx_altsums(const uint8_t* __restrict__ sr
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
                     const int t = fx_row16_sum(act ? s[c] : 0);
-                    if ((tid & 15) == 0) atomicAdd(&sred[r - r0][c], t);
+                    if ((tid & 15) == 0) sred[r - r0][c][tid >> 4] = t;
                 }
                 // column sums: bytes 0, 2 of each dword in one packed pair, bytes 1, 3 in the other; |wy| = 1, 2 or 3 (uniform)
                 const uint32_t aw = static_cast<uint32_t>(wy < 0 ? -wy : wy);
@@ -532,65 +686,100 @@ __global__ __launch_bounds__(256) void fx_altsums(const uint8_t* __restrict__ sr
         dstp[2] = make_int4(o[8], o[9], o[10], o[11]);
     }
     __syncthreads();
-    if (tid < (r1 - r0) * 3) srow_part[((static_cast<size_t>(f) * nbatches + batch) * rows + r0) * 3 + tid] = (&sred[0][0])[tid];
+    if (tid < (r1 - r0) * 3) {
+        const int* p16 = &sred[0][0][0] + 16 * tid;
+        int v = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += p16[k];
+        srow_part[((static_cast<size_t>(f) * nbatches + batch) * rows + r0) * 3 + tid] = v;
+        (&sred[0][0][0])[16 * tid] = v;                    // (slot 0 of its own 16: nobody else reads or writes it any more)
+    }
+    __syncthreads();
+    if (tid < 3) {
+        long long z = 0;
+        for (int r = r0; r < r1; ++r) z += static_cast<long long>(mx_alt_weight(r, rows, pad)) * sred[r - r0][tid][0];
+        zpart[((static_cast<size_t>(f) * nbands + band) * nbatches + batch) * 3 + tid] = z;
+    }
 }
 
-// grid (row blocks + column blocks, frames), 256 threads.  Row blocks: qrow for 256 rows of V each.  Column blocks: qcol for 256
-// values e = 3 x + c each -- Ccol over the bands into LDS (with the taps' reach on both sides), the row convolution in double.
-// Every column block sums Z itself (3 rows values, integers).   taps: 2 pad + 1 floats, centre at pad.
-__global__ __launch_bounds__(256) void fx_quirk_terms(const int* __restrict__ srow_part, const int* __restrict__ cpart, const float* __restrict__ taps,
-                                                      float* __restrict__ qrow, float* __restrict__ qcol, int rows, int cols, int pad, int pada, int qrows, int qpitch,
-                                                      int nbands, int nbatches, int nrowblocks, float dr, float dc)
+// grid (row blocks + value blocks + 1, frames), 256 threads.  Row blocks: qrow for 256 rows of V each (Srow = the batches' parts added
+// up).  Value blocks: ccol[f][e] = the bands' parts of Ccol added up, 256 values e = 3 x + c each.  The last block: zsum[f][c] = Z.
+__global__ __launch_bounds__(256) void fx_quirk_reduce(const int* __restrict__ srow_part, const int* __restrict__ cpart, const long long* __restrict__ zpart,
+                                                       float* __restrict__ qrow, int* __restrict__ ccol, double* __restrict__ zsum, int rows, int cols, int pad, int pada,
+                                                       int qrows, int nbands, int nbatches, int nrowblocks, int nvalblocks, float dr)
 {
-    extern __shared__ __attribute__((aligned(16))) unsigned char fxq_lds[];
-    __shared__ double zs[3][256];
     const int f = blockIdx.y, tid = threadIdx.x;
-    const double sp = (pad & 1) ? -1.0 : 1.0;
-    const int* sr = srow_part + static_cast<size_t>(f) * nbatches * rows * 3;
-    auto srow = [&](int r, int c) {                  // Srow: the batches' parts added up (integers)
-        int v = 0;
-        for (int b = 0; b < nbatches; ++b) v += sr[(static_cast<size_t>(b) * rows + r) * 3 + c];
-        return v;
-    };
     if (static_cast<int>(blockIdx.x) < nrowblocks) {
         const int re = blockIdx.x * 256 + tid;
-        if (re < qrows) {
-            const int r = mx_refl(re - pada, rows);
-            for (int c = 0; c < 3; ++c) qrow[(static_cast<size_t>(f) * 3 + c) * qrows + re] = static_cast<float>(static_cast<double>(dr) * sp * srow(r, c));
+        if (re >= qrows) return;
+        const double sp = (pad & 1) ? -1.0 : 1.0;
+        const int r = mx_refl(re - pada, rows);
+        const int* sr = srow_part + (static_cast<size_t>(f) * nbatches * rows + r) * 3;
+        for (int c = 0; c < 3; ++c) {
+            int v = 0;
+            for (int b = 0; b < nbatches; ++b) v += sr[static_cast<size_t>(b) * rows * 3 + c];
+            qrow[(static_cast<size_t>(f) * 3 + c) * qrows + re] = static_cast<float>(static_cast<double>(dr) * sp * v);
         }
         return;
     }
-    double z[3] = { 0, 0, 0 };
-    for (int r = tid; r < rows; r += 256) {
-        const double wy = static_cast<double>(mx_alt_weight(r, rows, pad));
-        for (int c = 0; c < 3; ++c) z[c] += wy * srow(r, c);
-    }
-    for (int c = 0; c < 3; ++c) zs[c][tid] = z[c];
-    __syncthreads();
-    for (int o = 128; o >= 1; o >>= 1) {
-        if (tid < o) for (int c = 0; c < 3; ++c) zs[c][tid] += zs[c][tid + o];
+    if (static_cast<int>(blockIdx.x) == nrowblocks + nvalblocks) {
+        __shared__ long long zs[3][256];
+        const int nz = nbands * nbatches;
+        long long z[3] = { 0, 0, 0 };
+        for (int i = tid; i < nz; i += 256)
+            for (int c = 0; c < 3; ++c) z[c] += zpart[(static_cast<size_t>(f) * nz + i) * 3 + c];
+        for (int c = 0; c < 3; ++c) zs[c][tid] = z[c];
         __syncthreads();
+        for (int o = 128; o >= 1; o >>= 1) {
+            if (tid < o) for (int c = 0; c < 3; ++c) zs[c][tid] += zs[c][tid + o];
+            __syncthreads();
+        }
+        if (tid < 3) zsum[static_cast<size_t>(f) * 3 + tid] = static_cast<double>(zs[tid][0]);
+        return;
     }
-    const int e0 = (blockIdx.x - nrowblocks) * 256;
+    const int e = (blockIdx.x - nrowblocks) * 256 + tid;
+    if (e >= 3 * cols) return;
+    const int* cp = cpart + static_cast<size_t>(f) * nbands * (3 * cols) + e;
+    int sum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    int b = 0;
+    for (; b + 8 <= nbands; b += 8) {                       // eight independent loads per trip
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum[j] += cp[static_cast<size_t>(b + j) * (3 * cols)];
+    }
+    for (; b < nbands; ++b) sum[0] += cp[static_cast<size_t>(b) * (3 * cols)];
+    ccol[static_cast<size_t>(f) * 3 * cols + e] = ((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]));
+}
+
+// grid (blocks of 256 values e = 3 x + c, frames), 256 threads: qcol = dc (-1)^pad (rowconv(Ccol)(x) + dr (-1)^(x+pad) Z), the row
+// convolution in double over an LDS tile of Ccol with the taps' reach on both sides (taps in LDS too).
+// taps: 2 pad + 1 floats, centre at pad.  dynamic LDS: nval ints + (2 pad + 1) floats
+__global__ __launch_bounds__(256) void fx_quirk_cols(const int* __restrict__ ccol, const double* __restrict__ zsum, const float* __restrict__ taps,
+                                                     float* __restrict__ qcol, int cols, int pad, int qpitch, int tileints, float dr, float dc)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char fxq_lds[];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    const int e0 = blockIdx.x * 256;
     // pixels whose column sums this block's outputs read: [xa, xb] inside the image (reflect-101 maps into it)
     const int xa = max(0, e0 / 3 - pad), xb = min(cols - 1, (e0 + 255) / 3 + pad), nval = 3 * (xb - xa + 1);
     int* cc = reinterpret_cast<int*>(fxq_lds);
-    const int* cp = cpart + static_cast<size_t>(f) * nbands * (3 * cols) + 3 * xa;
-    for (int i = tid; i < nval; i += 256) {
-        int sum = 0;
-        for (int b = 0; b < nbands; ++b) sum += cp[static_cast<size_t>(b) * (3 * cols) + i];
-        cc[i] = sum;
-    }
+    float* tp = reinterpret_cast<float*>(fxq_lds) + tileints;
+    for (int i = tid; i < nval; i += 256) cc[i] = ccol[static_cast<size_t>(f) * 3 * cols + 3 * xa + i];
+    for (int i = tid; i < 2 * pad + 1; i += 256) tp[i] = taps[i];
     __syncthreads();
     const int e = e0 + tid;
     if (e >= qpitch) return;
     const int x = e / 3, c = e - 3 * x;
     float out = 0.f;
     if (x < cols) {
-        double acc = 0;
-        for (int t = -pad; t <= pad; ++t) acc += static_cast<double>(taps[t + pad]) * cc[3 * (mx_refl(x + t, cols) - xa) + c];
-        const double sx = ((x + pad) & 1) ? -1.0 : 1.0;
-        out = static_cast<float>(static_cast<double>(dc) * sp * (acc + static_cast<double>(dr) * sx * zs[c][0]));
+        double acc[4] = { 0, 0, 0, 0 };
+        int t = -pad;
+        for (; t + 4 <= pad + 1; t += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += static_cast<double>(tp[t + j + pad]) * cc[3 * (mx_refl(x + t + j, cols) - xa) + c];
+        }
+        for (; t <= pad; ++t) acc[0] += static_cast<double>(tp[t + pad]) * cc[3 * (mx_refl(x + t, cols) - xa) + c];
+        const double sp = (pad & 1) ? -1.0 : 1.0, sx = ((x + pad) & 1) ? -1.0 : 1.0;
+        out = static_cast<float>(static_cast<double>(dc) * sp * (((acc[0] + acc[1]) + (acc[2] + acc[3])) + static_cast<double>(dr) * sx * zsum[static_cast<size_t>(f) * 3 + c]));
     }
     qcol[static_cast<size_t>(f) * qpitch + e] = out;
 }
@@ -599,24 +788,30 @@ __global__ __launch_bounds__(256) void fx_quirk_terms(const int* __restrict__ sr
 // ---- launcher ----------------------------------------------------------------------------------------------------------
 struct FxEntry {
     int nkb;
-    hipError_t (*blur_u8)(hipStream_t, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const float* qrow, const float* qcol, int qpitch);
+    hipError_t (*blur_u8)(hipStream_t, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const float* qrow, const float* qcol, int qpitch,
+                          const uint8_t* strips);
 };
 
 template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const float* qrow,
-                                           const float* qcol, int qpitch)
+                                           const float* qcol, int qpitch, const uint8_t* strips)
 {
     using C = FxCfg<NKB>;
     const int chunks = (g.cols + kFxChunk - 1) / kFxChunk;
-    const long long strips = static_cast<long long>(chunks) * g.nframes;
-    if (strips <= 0) return hipSuccess;
-    // segments per strip: a segment repeats NT steps of run-in, so as few as fill the chip about once
-    int tps = ((g.ntiles + C::NT - 1) / C::NT) * C::NT;
-    while (tps > C::NT && strips * ((g.ntiles + tps - 1) / tps) < static_cast<long long>(num_cus)) tps -= C::NT;
-    // evenly sized segments
-    int nseg = (g.ntiles + tps - 1) / tps;
-    tps = (((g.ntiles + nseg - 1) / nseg + C::NT - 1) / C::NT) * C::NT;
-    nseg = (g.ntiles + tps - 1) / tps;
-    const long long ntasks = strips * nseg;
+    const long long nstripes = static_cast<long long>(chunks) * g.nframes;
+    if (nstripes <= 0) return hipSuccess;
+    // Segments per strip of columns: a segment of t tiles takes t + NT steps (NT of run-in), and the chip runs num_cus tasks at a
+    // time; take the number of segments with the shortest makespan = rounds x steps per task (one segment unless the strips
+    // are too few to fill the chip: 240 strips of a 4K batch of 8 stay whole, a single 4K frame is cut in 8)
+    int nseg = 1, tps = ((g.ntiles + C::NT - 1) / C::NT) * C::NT;
+    {
+        long long best = -1;
+        for (int n = 1; n <= (g.ntiles + C::NT - 1) / C::NT; ++n) {
+            const int t = (((g.ntiles + n - 1) / n + C::NT - 1) / C::NT) * C::NT, ns = (g.ntiles + t - 1) / t;
+            const long long rounds = (nstripes * ns + num_cus - 1) / num_cus, span = rounds * (t + C::NT);
+            if (best < 0 || span < best) { best = span; nseg = ns; tps = t; }
+        }
+    }
+    const long long ntasks = nstripes * nseg;
     const int per_xcd = static_cast<int>((ntasks + 7) / 8);
     const dim3 grid(static_cast<unsigned>(8 * per_xcd));
     static bool attr_done = false;
@@ -629,10 +824,10 @@ template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, u
     }
     if (qrow)
         hipLaunchKernelGGL((fx_blur_u8<NKB, true>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg,
-                           static_cast<int>(ntasks), qrow, qcol, qpitch);
+                           static_cast<int>(ntasks), qrow, qcol, qpitch, strips);
     else
         hipLaunchKernelGGL((fx_blur_u8<NKB, false>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg,
-                           static_cast<int>(ntasks), qrow, qcol, qpitch);
+                           static_cast<int>(ntasks), qrow, qcol, qpitch, strips);
     return hipGetLastError();
 }
 

@@ -27,10 +27,22 @@ if check:
         print("%4d x %4d sigma %.1f n %d: max diff %d, differing %.2e, family %d%s" % (
             rows, cols, sigma, n, int(d.max()), float((d != 0).float().mean()), ctx.last_family(),
             "" if bad.numel() == 0 else "  first bad at %s (of %d)" % (bad[0].tolist(), bad.shape[0])), flush=True)
+if check:
+    # extreme images: alternating 0 / 255 columns, rows, checkerboard (the quirk's terms overflow the byte range: wrap semantics)
+    for name, fn in (("cols", lambda y, x: (x & 1) * 255), ("rows", lambda y, x: (y & 1) * 255), ("checker", lambda y, x: ((x ^ y) & 1) * 255)):
+        rows, cols = 300, 520
+        y = torch.arange(rows, device="cuda").view(rows, 1, 1).expand(rows, cols, 3)
+        x = torch.arange(cols, device="cuda").view(1, cols, 1).expand(rows, cols, 3)
+        fr = fn(y, x).to(torch.uint8).contiguous().view(1, rows, cols, 3)
+        a = ctx.pffft_(fr, 20.0, out=torch.empty_like(fr), nyquist_quirk=quirk, engine="matrix")
+        b = ctx.pffft_(fr, 20.0, out=torch.empty_like(fr), nyquist_quirk=quirk, engine="fused")
+        d = (a.int() - b.int()).abs()
+        d = torch.minimum(d, 256 - d)
+        print("extreme %-8s: max diff (mod 256) %d, differing %.2e, output range %d..%d" % (name, int(d.max()), float((d != 0).float().mean()), int(b.min()), int(b.max())), flush=True)
 rows, cols, sigma = 2160, 3840, 20.0
 frames = torch.randint(0, 256, (nf, rows, cols, 3), dtype=torch.uint8, device="cuda", generator=g)
 out = torch.empty_like(frames)
-for eng in ("fused", "matrix", "fused"):
+for eng in (("fused", "fused") if "--fused-only" in sys.argv else ("fused", "matrix", "fused")):
     for _ in range(10):
         ctx.pffft_(frames, sigma, out=out, nyquist_quirk=quirk, engine=eng)
     torch.cuda.synchronize()
