@@ -93,6 +93,10 @@ def fft_plan_radices(n):
 
 
 # ---- the GPU context ------------------------------------------------------------------
+# enum blur_engine (include/blur_amd.h)
+ENGINES = {"auto": 0, "rows-first": 1, "wave-resident": 2, "matrix": 3, "fft": 5, "fused": 6}
+
+
 class BlurContext:
     """Owns the plan / kernel-spectrum caches and the float32 workspace on one GPU
     (role of the PFFFT_Setup pair the reference rebuilds per call, Source.cpp:477-478)."""
@@ -126,17 +130,18 @@ class BlurContext:
         self._lib.blur_opts_default(C.byref(o))
         o.nyquist_quirk = 1 if nyquist_quirk else 0
         o.col_group = int(col_group)
-        o.reserved[0] = 1 if force_generic else 0   # tests: run the run-time-planned kernels even where a specialised one exists
-        o.reserved[1] = int(frames_per_launch)
-        o.reserved[2] = 1 if row_major_planes else 0
+        o.force_generic = 1 if force_generic else 0   # tests: run the run-time-planned kernels even where a specialised one exists
+        o.frames_per_launch = int(frames_per_launch)
+        o.row_major_planes = 1 if row_major_planes else 0
         # wave-resident kernels (transform length 256 * R0, columns first): None = where they pay (the image fills most
         # of the transform), False = never, True = wherever the image fits one
-        o.reserved[3] = 0 if wave_resident is None else (2 if wave_resident else 1)
-        # engine: None = the library's choice (the matrix-core kernels wherever one exists for the kernel width, the FFT
-        # kernels otherwise); "matrix" = Toeplitz products on the f16 matrix cores (mx_kernels.hpp); "fft" = the FFT kernels
-        # with their own measured choice of family; "wave-resident" / "rows-first" = one FFT family
+        o.engine = 0 if wave_resident is None else (2 if wave_resident else 1)
+        # engine (enum blur_engine): None = the library's choice (the fused matrix-core kernel where it applies, else the two-kernel
+        # matrix-core engine, else the FFT kernels); "fused" / "matrix" = Toeplitz products on the f16 matrix cores in one kernel
+        # (fx_kernels.hpp) / two (mx_kernels.hpp); "fft" = the FFT kernels with their own measured choice of family;
+        # "wave-resident" / "rows-first" = one FFT family
         if engine is not None:
-            o.reserved[3] = {"matrix": 3, "wave-resident": 2, "rows-first": 1, "fft": 5, "fused": 6}[engine]
+            o.engine = ENGINES[engine]
         return o
 
     def use_torch_stream(self):
@@ -310,9 +315,9 @@ class BlurContext:
                                                    float(nsmooth), C.byref(o)))
         return dst
 
-    def separable(self, image, taps, pad=None, out=None, nyquist_quirk=True):
-        """any symmetric separable kernel (odd tap count) through the same engine; pad defaults to len(taps)//2"""
-        o = self._opts(nyquist_quirk)
+    def separable(self, image, taps, pad=None, out=None, nyquist_quirk=True, engine=None):
+        """any symmetric separable kernel (odd tap count) through the same engines; pad defaults to len(taps)//2"""
+        o = self._opts(nyquist_quirk, engine=engine)
         t = np.ascontiguousarray(taps, np.float32)
         dst = image if out is None else out
         self.use_torch_stream()
@@ -423,7 +428,7 @@ class BlurMulti:
         o = BlurOpts()
         self._lib.blur_opts_default(C.byref(o))
         o.nyquist_quirk = 1 if nyquist_quirk else 0
-        o.reserved[3] = 0 if wave_resident is None else (2 if wave_resident else 1)
+        o.engine = 0 if wave_resident is None else (2 if wave_resident else 1)
         if isinstance(frames, np.ndarray):
             a = np.ascontiguousarray(frames, np.uint8)
             if a.ndim != 4 or a.shape[3] != 3:

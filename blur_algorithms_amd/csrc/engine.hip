@@ -958,8 +958,10 @@ static uint64_t fnv1a(const void* data, size_t bytes)
 
 // ---- matrix-core engine: tables ----------------------------------------------------------------------------------
 // taps of one axis from the reference's n-periodic kernel array (centre at index 0): taps[t + pad] = karr[(t + n) % n]
-static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz, const CustomKernel* ck, const MxTables** out)
+// quiet: a kernel the engine cannot hold is reported by the return value only (the caller falls back to another engine)
+static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz, const CustomKernel* ck, const MxTables** out, bool quiet = false)
 {
+    auto refuse = [&](int code, const char* msg) { return quiet ? code : fail(ctx, code, msg); };
     const int pad = sz.pad;
     std::vector<float> karr[2];                                  // row axis (n_row), column axis (n_col)
     const int nn[2] = { sz.n_row, sz.n_col };
@@ -971,7 +973,7 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
             karr[ax].assign(n, 0.f);
             if (ck->box_klen > 0) box_kernel_1d(karr[ax].data(), ck->box_klen, n);
             else {
-                if (ck->ksize > n) return fail(ctx, BLUR_ERR_INVALID, "kernel longer than the padded line");
+                if (ck->ksize > n) return refuse(BLUR_ERR_INVALID, "kernel longer than the padded line");
                 const int c = ck->ksize / 2;
                 for (int t = 0; t < ck->ksize; ++t) karr[ax][(t - c + n) % n] += ck->taps[t];
             }
@@ -994,14 +996,14 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
         for (int k = -pad; k <= pad; ++k) taps[k + pad] = karr[ax][(k + n) % n];
         // anything of the kernel array outside +-pad would be lost here: the Toeplitz band is 2 pad + 1 wide
         for (int i = pad + 1; i < n - pad; ++i)
-            if (karr[ax][i] != 0.f) return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: kernel wider than 2 pad + 1");
+            if (karr[ax][i] != 0.f) return refuse(BLUR_ERR_UNSUPPORTED, "matrix-core engine: kernel wider than 2 pad + 1");
         // the 24-bit intermediate of the kernels (mx_kernels.hpp) covers [0, 256): non-negative taps with sum <= 1 keep the
         // row pass inside 0..255.13 (the quirk's terms are added in f32 after it is decoded: no bound on them)
         {
             double sum = 0;
             bool neg = false;
             for (float t : taps) { sum += t; neg = neg || t < 0.f; }
-            if (neg || sum > 1.0005) return fail(ctx, BLUR_ERR_UNSUPPORTED, "matrix-core engine: taps must be non-negative with sum <= 1");
+            if (neg || sum > 1.0005) return refuse(BLUR_ERR_UNSUPPORTED, "matrix-core engine: taps must be non-negative with sum <= 1");
         }
         std::vector<uint16_t> fr(static_cast<size_t>(2) * nkb * 512);
         mx_fragments(taps.data(), pad, nkb, fr.data());
@@ -1024,8 +1026,9 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
     return BLUR_OK;
 }
 
+// ptrs_aligned: the frame pointers of the call are 4-byte aligned (a condition of the fused kernel)
 static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p, bool u8c3 = true,
-                   const CustomKernel* ck = nullptr, bool allow_wr = true)
+                   const CustomKernel* ck = nullptr, bool allow_wr = true, bool ptrs_aligned = false)
 {
     if (!ctx) return BLUR_ERR_INVALID;
     if (rows <= 0 || cols <= 0 || (!ck && !(sigma > 0))) return fail(ctx, BLUR_ERR_INVALID, "rows, cols and sigma must be positive");
@@ -1043,11 +1046,17 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         return fail(ctx, BLUR_ERR_UNSUPPORTED, "pad > min(rows, cols) - 1: reflect-101 would read outside the image (README.md:33-38)");
     const bool quirk = opts ? opts->nyquist_quirk != 0 : true;
     p.col_group = opts ? opts->col_group : 0;
-    const bool allow_fast = u8c3 && !(opts && opts->reserved[0] == 1);   // reserved[0] = 1: force the generic kernels (tests)
-    // Engine choice, blur_opts.reserved[3]:  0 the library's choice -- the matrix-core kernels (mx_kernels.hpp) wherever one is
-    // instantiated for the pad and the frame fits their 32-bit offsets, the FFT kernels otherwise;  3 the matrix-core kernels or
-    // an error;  1 / 2 / 5 the FFT kernels (1 never wave-resident, 2 wave-resident wherever it fits, 5 the measured FFT policy below).
-    const int choice = opts ? opts->reserved[3] : 0;
+    const bool allow_fast = u8c3 && !(opts && opts->force_generic == 1);   // force the generic kernels (tests)
+    // Engine choice (enum blur_engine).  The library's own policy, BLUR_ENGINE_AUTO, in the order it is applied:
+    //   | engine                      | where                                                   | measured (MI355X, 8 frames per call)            |
+    //   | fused matrix-core kernel    | pad <= 72 (sigma <~ 22), cols % 4 == 0, aligned frames,  | 4K sigma 20: 47 us per frame against 70 for the  |
+    //   |                             | non-negative taps with sum <= 1                         | two kernels and 105 for the FFT kernels          |
+    //   | FFT, compile-time families  | frames < 1 MP, or pad > 136 on frames >= 6 MP           | 1080p sigma 20 single frame 72 / 78 us;          |
+    //   |                             |                                                         | 4K sigma 50: 72 GP/s against 63                  |
+    //   | two-kernel matrix engine    | pad <= 168, non-negative taps with sum <= 1             | 4K sigma 26 / 30 / 36: 103 / 87 / 80 GP/s (FFT 76)|
+    //   | FFT kernels                 | everything else                                         |                                                   |
+    // The choice depends on the frame and the kernel only, never on the number of frames.
+    const int choice = opts ? opts->engine : BLUR_ENGINE_AUTO;
     // (allow_wr = false: the caller wants the rows-first float planes themselves, blur_rowpass_u8c3_dev)
     // Where the library's own choice (reserved[3] = 0) stays with the FFT kernels although a matrix-core kernel exists -- only
     // when the FFT engine has a compile-time family that its own policy below would pick (the run-time-planned kernels are
@@ -1077,16 +1086,24 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
             small_fft = wr_pays || old_both;
         }
     }
-    if (allow_fast && allow_wr && choice == 6) {
+    if (allow_fast && allow_wr && (choice == BLUR_ENGINE_FUSED || choice == BLUR_ENGINE_AUTO)) {
         const FxEntry* fe = find_fx_entry(p.sz.pad);
-        if (!fe) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: no kernel instantiated for this pad");
-        if (static_cast<long long>(rows) * cols * 3 >= (1ll << 32)) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: frame too large for 32-bit offsets");
-        if ((cols & 3) != 0) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: the image width must be a multiple of 4");
-        if (int rc = mx_get_tables(ctx, fe->nkb, sigma, p.sz, ck, &p.mxt)) return rc;
-        p.fx = fe;
-        p.mx_quirk = quirk;
-        p.frame_elems = 0;
-        return BLUR_OK;
+        const char* why = nullptr;
+        if (!fe) why = "fused matrix-core engine: no kernel instantiated for this pad";
+        else if (static_cast<long long>(rows) * cols * 3 >= (1ll << 32)) why = "fused matrix-core engine: frame too large for 32-bit offsets";
+        else if ((cols & 3) != 0) why = "fused matrix-core engine: the image width must be a multiple of 4";
+        else if (!ptrs_aligned) why = "fused matrix-core engine: frame pointers must be 4-byte aligned";
+        if (why && choice == BLUR_ENGINE_FUSED) return fail(ctx, BLUR_ERR_UNSUPPORTED, why);
+        if (!why) {
+            const int rc = mx_get_tables(ctx, fe->nkb, sigma, p.sz, ck, &p.mxt, choice == BLUR_ENGINE_AUTO);
+            if (rc != BLUR_OK && choice == BLUR_ENGINE_FUSED) return rc;
+            if (rc == BLUR_OK) {
+                p.fx = fe;
+                p.mx_quirk = quirk;
+                p.frame_elems = 0;
+                return BLUR_OK;
+            }
+        }
     }
     if (allow_fast && allow_wr && !small_fft && (choice == 0 || choice == 3)) {
         const MxEntry* me = find_mx_entry(p.sz.pad);
@@ -1095,7 +1112,7 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         if (!fits && choice != 0)
             return fail(ctx, BLUR_ERR_UNSUPPORTED, me ? "matrix-core engine: frame too large for 32-bit element offsets" : "matrix-core engine: no kernel instantiated for this pad");
         int rc_tables = BLUR_OK;
-        if (fits) rc_tables = mx_get_tables(ctx, me->nkb, sigma, p.sz, ck, &p.mxt);
+        if (fits) rc_tables = mx_get_tables(ctx, me->nkb, sigma, p.sz, ck, &p.mxt, choice == BLUR_ENGINE_AUTO);
         if (fits && rc_tables != BLUR_OK && choice != 0) return rc_tables;
         if (fits && rc_tables == BLUR_OK) {
         p.mx = me;
@@ -1106,14 +1123,14 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         }
     }
     // Wave-resident kernels first (reserved[3] = 1 switches them off): both passes need one, and its LDS must hold the image
-    if (allow_fast && allow_wr && !(opts && opts->reserved[3] == 1)) {
+    if (allow_fast && allow_wr && !(opts && opts->engine == BLUR_ENGINE_FFT_ROWS_FIRST)) {
         const WrEntry* wc = find_wr_entry(rows + 2 * p.sz.pad, true);
         const WrEntry* wr = find_wr_entry(cols + 2 * p.sz.pad, false);
         // Default policy (reserved[3] = 2: wherever the image fits).  Measured on MI355X, us per frame, wave-resident against
         // rows-first: 4K sigma 20 106 / 107 (both families specialised: equal; the wave-resident pair writes whole sectors
         // only, HBM traffic 1.00x algorithmic); 1080p sigma 20 41 / 36 (5 x 256 columns fill 5 of 16 wave slots);
         // 1000 x 1500 sigma 38.7 32 / 144 and 1300 x 1950 sigma 44 83 / 87 (no specialised rows-first kernel: run-time plans).
-        bool pays = opts && opts->reserved[3] == 2;
+        bool pays = opts && opts->engine == BLUR_ENGINE_FFT_WAVE_RESIDENT;
         if (!pays && wc && wr) {
             const int need_c = rows + 2 * p.sz.pad, need_r = cols + 2 * p.sz.pad, nc = wc->r0 * kWrS, nr = wr->r0 * kWrS;
             const bool old_both = find_fast_entry(p.sz.n_col, true) && find_fast_entry(p.sz.n_row, false);
@@ -1184,7 +1201,7 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         if (int rc = get_spectrum(ctx, *p.col, sigma, p.sz.kSize, quirk, &p.m_col)) return rc;
     }
     // strip layout of the intermediate only when both kernels understand it
-    const bool no_tile = opts && opts->reserved[2] == 1;
+    const bool no_tile = opts && opts->row_major_planes == 1;
     p.tile_w = (p.row->fast && p.col->fast && p.col_fast_c == 4 && !no_tile) ? 8 : 0;
     // strip layout: [strip][row pair][8 columns][2 rows] per channel
     p.frame_elems = p.tile_w ? static_cast<size_t>((cols + p.tile_w - 1) / p.tile_w) * ((rows + 1) / 2) * (2 * p.tile_w) * 3
@@ -1593,7 +1610,8 @@ static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_
     if (!ctx) return BLUR_ERR_INVALID;
     if (!d_src || !d_dst || nframes < 0) return fail(ctx, BLUR_ERR_INVALID, "null frame pointer or negative frame count");
     Prepared p;
-    if (int rc = prepare(ctx, rows, cols, sigma, opts, p, true, ck)) return rc;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(d_src) | reinterpret_cast<uintptr_t>(d_dst)) & 3) == 0;
+    if (int rc = prepare(ctx, rows, cols, sigma, opts, p, true, ck, true, aligned)) return rc;
     const size_t px = static_cast<size_t>(rows) * cols;
     // Frames per launch pair.  Measured on MI355X (4K, sigma 20): 1 frame 0.170 ms/frame, 2: 0.148, 4: 0.143,
     // 8: 0.140 -- the kernels are latency bound, not HBM bound, so filling every CU evenly and amortising
@@ -1604,7 +1622,7 @@ static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_
         ctx->last_family = 6;
         return run_fx_u8c3(ctx, d_src, d_dst, nframes, rows, cols, p);
     }
-    int chunk = opts && opts->reserved[1] > 0 ? opts->reserved[1] : static_cast<int>((1024u << 20) / (p.frame_elems * sizeof(float)));
+    int chunk = opts && opts->frames_per_launch > 0 ? opts->frames_per_launch : static_cast<int>((1024u << 20) / (p.frame_elems * sizeof(float)));
     if (chunk < 1) chunk = 1;
     if (chunk > nframes) chunk = nframes;
     if (nframes == 0) return BLUR_OK;

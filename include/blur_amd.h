@@ -38,6 +38,20 @@ enum {
 
 typedef struct blur_ctx blur_ctx;
 
+/* blur_opts.engine.  Every engine computes the same blur under the same parity contract (Parity); the choice is
+   about speed and about what each engine can hold.  engine.hip: prepare() holds the policy table of BLUR_ENGINE_AUTO. */
+enum blur_engine {
+    BLUR_ENGINE_AUTO = 0,            /* fused matrix-core kernel where it exists for the kernel's half width (pad <= 72), the image
+                                        width is a multiple of 4 and the frame pointers are 4-byte aligned; else the two-kernel
+                                        matrix-core engine (pad <= 168, non-negative taps) except where the FFT engine has a
+                                        faster compile-time family (small frames, very wide kernels on 4K frames); else FFT */
+    BLUR_ENGINE_FFT_ROWS_FIRST = 1,  /* FFT kernels, never the wave-resident family */
+    BLUR_ENGINE_FFT_WAVE_RESIDENT = 2, /* FFT kernels, wave-resident (transform length 256 R0, columns first) wherever the image fits */
+    BLUR_ENGINE_MATRIX = 3,          /* two-kernel matrix-core engine (mx_kernels.hpp); BLUR_ERR_UNSUPPORTED if it cannot hold the kernel */
+    BLUR_ENGINE_FFT = 5,             /* FFT kernels with their own measured choice of family */
+    BLUR_ENGINE_FUSED = 6            /* fused matrix-core kernel (fx_kernels.hpp); BLUR_ERR_UNSUPPORTED where it does not apply */
+};
+
 /* Options of the whole-image blur.  Zero-initialise, then blur_opts_default(). */
 typedef struct blur_opts {
     /* 1 (default): reproduce pffft_sorted_optimized_convolution exactly
@@ -47,20 +61,17 @@ typedef struct blur_opts {
     int nyquist_quirk;
     /* columns per workgroup of the column pass (0 = auto: 8 or less as LDS allows) */
     int col_group;
-    /* reserved[0] = 1: use the run-time-planned kernels even where a compile-time specialised
-       one exists (tests); reserved[1] > 0: frames per launch pair of the batch entry point
-       (0 = auto: as many as fit a 1 GiB float workspace);
-       reserved[2] = 1: keep the float intermediate in row-major planes even when both passes are
-       specialised (default: strips of 8 columns stored contiguously);
-       reserved[3]: which kernels run the u8c3 blur.  0 = the library's choice: the matrix-core kernels
-       (mx_kernels.hpp: both passes as banded Toeplitz products on the f16 MFMA units) where one is
-       instantiated for the kernel's half width (pad <= 168) -- except small frames and very wide kernels on
-       large frames when the FFT engine has a compile-time family for them (engine.hip: prepare()) -- and the
-       FFT kernels otherwise;
-       3 = the matrix-core kernels (BLUR_ERR_UNSUPPORTED if none fits);
-       5 = the FFT kernels with their own measured choice of family, 1 = FFT, never the wave-resident family,
-       2 = FFT, wave-resident (transform length 256 * R0, columns first) wherever the image fits (tests, A/B timing) */
-    int reserved[6];
+    /* 1: use the run-time-planned FFT kernels even where a compile-time specialised one exists (tests) */
+    int force_generic;
+    /* > 0: frames per launch pair of the batch entry point (0 = auto: as many as fit a 1 GiB float workspace;
+       the fused matrix-core engine has no workspace and takes the whole batch in one launch) */
+    int frames_per_launch;
+    /* 1: keep the FFT engine's float intermediate in row-major planes even when both passes are specialised
+       (default: strips of 8 columns stored contiguously) */
+    int row_major_planes;
+    /* which kernels run the u8c3 blur: one of enum blur_engine; 0 = the library's choice */
+    int engine;
+    int reserved[2];   /* must be zero */
 } blur_opts;
 
 void blur_opts_default(blur_opts* o);
@@ -240,7 +251,8 @@ int blur_gaussian_u8c3_batch_multi_host(blur_multi* m, const uint8_t* src, uint8
    convolved independently.  n must be a length the wave-resident kernels support: blur_wr_length(). */
 int blur_convolve_lines_c32_dev(blur_ctx* ctx, const float* d_in, float* d_out, int nlines, int n, const float* multipliers);
 /* ---- matrix-core engine (mx_kernels.hpp): both passes as banded Toeplitz products on v_mfma_f32_32x32x16_f16 ----
-   blur_opts.reserved[3] = 3 selects it for the u8c3 entry points.  Same linear map as the FFT product inside the
+   blur_opts.engine = BLUR_ENGINE_MATRIX selects it for the u8c3 entry points (BLUR_ENGINE_FUSED: the one-kernel form of the same
+   products, fx_kernels.hpp, which is the library's own choice where it applies).  Same linear map as the FFT product inside the
    crop (Source.cpp:536,558), Nyquist-slot quirk (Source.cpp:420-425) included as a rank-one term per line.
    blur_mx_window_blocks(pad): window blocks (of 16 positions) of the kernel instantiated for this pad, 0 = none.
    blur_mx_fragments: the Toeplitz operand fragments the kernels load, [2][nkb][64][8] binary16 (hi, lo halves of

@@ -1,0 +1,178 @@
+"""The fused matrix-core kernel (fx_kernels.hpp: row pass, register hand-off, column pass and byte emission in one launch, the
+library's choice where it applies) against the float64 oracle under the same parity contract as every other engine."""
+import numpy as np
+import pytest
+
+from conftest import assert_u8_parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _rand_img(rows, cols, seed):
+    return np.random.default_rng(seed).integers(0, 256, (rows, cols, 3), dtype=np.uint8)
+
+
+def _fam(ctx):
+    return ctx.last_family()
+
+
+# widths are multiples of 4 (a condition of the kernel); heights are anything; below one chunk of 128 columns, exactly one,
+# several with a ragged last one; heights below one tile of 32 rows (pad + 1 at least), ragged last tiles
+SHAPES = [(270, 480, 20.0), (200, 332, 20.0), (131, 152, 18.0), (540, 960, 21.5), (97, 644, 19.0), (1080, 1920, 20.0), (70, 68, 20.0), (100, 100, 20.0),
+          (67, 256, 19.0), (300, 72, 20.0), (66, 132, 20.0)]
+
+
+@pytest.mark.parametrize("rows,cols,sigma", SHAPES)
+@pytest.mark.parametrize("quirk", [False, True])
+def test_fused_engine_matches_the_oracle(ctx, rows, cols, sigma, quirk):
+    from oracle import oracle as O
+    torch = _torch()
+    img = _rand_img(rows, cols, rows + 3 * cols)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=quirk, want_planes=True)
+    got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, nyquist_quirk=quirk, engine="fused").cpu().numpy()
+    assert _fam(ctx) == 6
+    assert_u8_parity(got, want, planes)
+    # the library's own choice is this kernel, byte for byte
+    auto = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, nyquist_quirk=quirk).cpu().numpy()
+    assert _fam(ctx) == 6
+    assert np.array_equal(auto, got)
+
+
+# one sigma per instantiated window size (NKB = 3, 5, 7, 9, 11: pad <= 8, 24, 40, 56, 72); sigma 2.0 is the truncated Gaussian
+# whose alternating sum is most negative (Nyquist gain 1.0037)
+EVERY_WINDOW = [(2.0, 3), (2.5, 3), (7.5, 5), (12.5, 7), (17.0, 9), (22.0, 11)]
+
+
+@pytest.mark.parametrize("sigma,nkb", EVERY_WINDOW)
+def test_every_instantiated_window_of_the_fused_kernel(ctx, sigma, nkb):
+    import blur_algorithms_amd as B
+    from oracle import oracle as O
+    torch = _torch()
+    rows, cols = 171 + 2 * nkb, 332
+    pad = B.pffft_sizing(rows, cols, sigma)["pad"]
+    assert 8 * (nkb - 4) < pad <= 8 * (nkb - 2) or nkb == 3
+    img = _rand_img(rows, cols, nkb)
+    for quirk in (True, False):
+        want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=quirk, want_planes=True)
+        got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, nyquist_quirk=quirk, engine="fused").cpu().numpy()
+        assert _fam(ctx) == 6
+        assert_u8_parity(got, want, planes)
+
+
+def test_fused_engine_batch_segments_in_place_and_constant(ctx):
+    """a frame blurred alone (its strips of columns are cut into segments of tiles to fill the chip) and inside a batch (whole
+    strips) gives the same bytes; in place (the reference's calling convention, Source.cpp:429) equals out of place; a constant
+    image stays constant"""
+    torch = _torch()
+    frames = torch.from_numpy(np.random.default_rng(9).integers(0, 256, (3, 470, 388, 3), dtype=np.uint8)).cuda()
+    batch = ctx.pffft_(frames, 20.0, out=torch.empty_like(frames), engine="fused")
+    for i in range(3):
+        one = ctx.pffft_(frames[i], 20.0, out=torch.empty_like(frames[i]), engine="fused")
+        assert torch.equal(one, batch[i])
+    inplace = frames.clone()
+    ctx.pffft_(inplace, 20.0, out=inplace, engine="fused")
+    assert torch.equal(inplace, batch)
+    const = torch.full((200, 300, 3), 201, dtype=torch.uint8, device="cuda")
+    assert int((ctx.pffft_(const.clone(), 20.0, engine="fused") != 201).sum()) == 0
+
+
+def test_fused_engine_extreme_images(ctx):
+    """columns / rows alternating 0 and 255 (the quirk's row / column term is +-255 on top of 127.5: values past the byte range
+    wrap like (uint8_t)(v + 0.5f) does on x86), checkerboard, all 255, all 0"""
+    from oracle import oracle as O
+    torch = _torch()
+    rows, cols, sigma = 150, 264, 20.0
+    x = np.arange(cols)[None, :, None]
+    y = np.arange(rows)[:, None, None]
+    for name, img in (("columns", np.broadcast_to(255 * (x & 1), (rows, cols, 3))), ("rows", np.broadcast_to(255 * (y & 1), (rows, cols, 3))),
+                      ("checker", np.broadcast_to(255 * ((x + y) & 1), (rows, cols, 3))), ("white", np.full((rows, cols, 3), 255)), ("black", np.zeros((rows, cols, 3)))):
+        img = np.ascontiguousarray(img).astype(np.uint8)
+        want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=True, want_planes=True)
+        got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, engine="fused").cpu().numpy()
+        assert_u8_parity(got, want, planes), name
+
+
+def test_where_the_fused_kernel_does_not_apply(ctx):
+    """an image width that is no multiple of 4, an unaligned frame pointer, a kernel wider than 145 taps: asking for the fused
+    kernel is an error, the library's own choice takes another engine and gives the oracle's bytes"""
+    from blur_algorithms_amd.api import BlurError
+    from oracle import oracle as O
+    torch = _torch()
+    img = _rand_img(210, 333, 5)
+    with pytest.raises(BlurError):
+        ctx.pffft_(torch.from_numpy(img).cuda(), 20.0, engine="fused")
+    want, planes = O.pffft_blur_u8c3_f64(img, 20.0, quirk=True, want_planes=True)
+    got = ctx.pffft_(torch.from_numpy(img).cuda(), 20.0).cpu().numpy()
+    assert _fam(ctx) != 6
+    assert_u8_parity(got, want, planes)
+    img4 = _rand_img(210, 332, 6)
+    with pytest.raises(BlurError):
+        ctx.pffft_(torch.from_numpy(img4).cuda(), 30.0, engine="fused")          # pad 98 > 72
+    buf = torch.zeros(img4.size + 16, dtype=torch.uint8, device="cuda")
+    off = buf[2:2 + img4.size].view(210, 332, 3)
+    off.copy_(torch.from_numpy(img4))
+    with pytest.raises(BlurError):
+        ctx.pffft_(off, 20.0, out=torch.empty_like(torch.from_numpy(img4).cuda()), engine="fused")
+    want, planes = O.pffft_blur_u8c3_f64(img4, 20.0, quirk=True, want_planes=True)
+    got = ctx.pffft_(off, 20.0, out=torch.empty_like(torch.from_numpy(img4).cuda())).cpu().numpy()
+    assert _fam(ctx) != 6
+    assert_u8_parity(got, want, planes)
+
+
+def test_fused_engine_metric_frame(ctx):
+    """the metric's own frame (3840 x 2160, sigma 20) whole against the float64 oracle, on the library's choice of engine"""
+    from oracle import oracle as O
+    torch = _torch()
+    img = _rand_img(2160, 3840, 2160)
+    want, planes = O.pffft_blur_u8c3_f64(img, 20.0, quirk=True, want_planes=True)
+    got = ctx.pffft_(torch.from_numpy(img).cuda(), 20.0).cpu().numpy()
+    assert _fam(ctx) == 6
+    n = assert_u8_parity(got, want, planes)
+    assert n < 2000
+
+
+def test_fused_engine_fuzz_time_boxed(ctx):
+    """random shapes (widths below one chunk of 128 columns, heights below one tile of 32 rows, ragged last chunks and tiles), random
+    sigma over every window size, both quirk settings, uniform and 0 / 255 images, in place and out of place, single frames and
+    small batches, against the float64 oracle; with redzones around the image buffers.  About 30 s."""
+    import time
+    from oracle import oracle as O
+    torch = _torch()
+    rng = np.random.default_rng(20261005)
+    t_end = time.time() + 30.0
+    cases = 0
+    while time.time() < t_end or cases < 15:
+        sigma = float(rng.choice([0.7, 1.5, 3.0, 6.0, 9.5, 14.0, 17.5, 20.0, 22.0]))
+        pad = O.pffft_sizing(4096, 4096, sigma)["pad"]
+        rows = int(rng.integers(pad + 1, pad + 300))
+        cols = (int(rng.integers(pad + 1, pad + 460)) + 3) & ~3
+        if O.pffft_sizing(rows, cols, sigma)["pad"] > min(rows, cols) - 1:
+            continue
+        quirk = bool(rng.integers(0, 2))
+        kind = rng.choice(["uniform", "binary"])
+        nf = int(rng.choice([1, 1, 2]))
+        img = rng.integers(0, 256, (nf, rows, cols, 3), dtype=np.uint8) if kind == "uniform" else (rng.integers(0, 2, (nf, rows, cols, 3)) * 255).astype(np.uint8)
+        guard = 4096
+        n = nf * rows * cols * 3
+        buf = torch.full((2 * n + 3 * guard,), 0xA5, dtype=torch.uint8, device="cuda")
+        src = buf[guard:guard + n].view(nf, rows, cols, 3)
+        dst = buf[2 * guard + n:2 * guard + 2 * n].view(nf, rows, cols, 3)
+        src.copy_(torch.from_numpy(img))
+        inplace = rng.random() < 0.3
+        got = ctx.pffft_(src, sigma, out=src if inplace else dst, nyquist_quirk=quirk, engine="fused").cpu().numpy()
+        try:
+            for i in range(nf):
+                want, planes = O.pffft_blur_u8c3_f64(img[i], sigma, quirk, want_planes=True)
+                assert_u8_parity(got[i], want, planes)
+            red = torch.cat([buf[:guard], buf[guard + n:2 * guard + n], buf[2 * guard + 2 * n:]])
+            assert int((red != 0xA5).sum()) == 0, "redzone overwritten"
+            if not inplace:
+                assert np.array_equal(src.cpu().numpy(), img), "source modified"
+        except AssertionError as e:
+            raise AssertionError("rows=%d cols=%d sigma=%r quirk=%d kind=%s inplace=%d frames=%d: %s" % (rows, cols, sigma, quirk, kind, inplace, nf, e))
+        cases += 1

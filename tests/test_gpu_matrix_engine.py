@@ -65,34 +65,40 @@ def test_every_instantiated_window(ctx, sigma, nkb):
 
 
 def test_the_librarys_choice_of_engine(ctx):
-    """blur_opts.reserved[3] = 0: the matrix-core kernels for frames of 1 MP and more whose kernel they can hold; the FFT
-    kernels for pad > 168, for kernels with negative taps (the 24-bit intermediate does not hold them) and for small frames
-    where the FFT engine has a compile-time family (fewer launches).  The choice never depends on the number of frames.
-    Asking for the matrix engine explicitly where it cannot run is an error."""
-    import ctypes as C
-    import blur_algorithms_amd as B
+    """BLUR_ENGINE_AUTO (include/blur_amd.h): the fused matrix-core kernel (family 6) where the kernel's half width is at most 72,
+    the width a multiple of 4 and the frames aligned; else the two-kernel matrix engine (family 4) for frames of 1 MP and more whose
+    kernel it can hold; the FFT kernels for pad > 168, for kernels with negative taps and for small frames or very wide kernels
+    where the FFT engine has a compile-time family.  The choice never depends on the number of frames.  Asking for an engine
+    explicitly where it cannot run is an error."""
     from blur_algorithms_amd.api import BlurError
     torch = _torch()
-    lib = B._lib.load()
-    lib.blur_debug_last_family.argtypes = [C.c_void_p]
-    lib.blur_debug_last_family.restype = C.c_int
-    fam = lambda: lib.blur_debug_last_family(ctx._h)
+    fam = ctx.last_family
     batch = torch.zeros((8, 1080, 1920, 3), dtype=torch.uint8, device="cuda")
     big = torch.zeros((3000, 4100, 3), dtype=torch.uint8, device="cuda")
     small = torch.from_numpy(_rand_img(400, 420, 1)).cuda()
+    odd = torch.zeros((2, 1080, 1921, 3), dtype=torch.uint8, device="cuda")
     ctx.pffft_(batch, 20.0)
+    assert fam() == 6
+    ctx.pffft_(batch[0], 20.0)                                    # one frame of the batch: the same engine as the batch
+    assert fam() == 6
+    ctx.pffft_(small.clone(), 20.0)                               # small frames too: one launch
+    assert fam() == 6
+    ctx.pffft_(odd, 20.0)                                         # width 1921: the two-kernel engine
     assert fam() == 4
-    ctx.pffft_(batch, 60.0)                                       # pad 195
-    assert fam() != 4
+    ctx.pffft_(batch, 30.0)                                       # pad 98: beyond the fused kernel's windows
+    assert fam() == 4
+    ctx.pffft_(batch, 60.0)                                       # pad 195: beyond every matrix-core window
+    assert fam() not in (4, 6)
     with pytest.raises(BlurError):
         ctx.pffft_(batch, 60.0, engine="matrix")
-    ctx.pffft_(small.clone(), 20.0)                               # 0.17 MP, wave-resident FFT kernels exist for 530 x 550 points
+    with pytest.raises(BlurError):
+        ctx.pffft_(batch, 30.0, engine="fused")
+    small_odd = torch.from_numpy(_rand_img(400, 421, 1)).cuda()
+    ctx.pffft_(small_odd, 20.0)                                   # 0.17 MP, wave-resident FFT kernels exist for 530 x 551 points
     assert fam() == 2
-    ctx.pffft_(batch[0], 20.0)                                    # one frame of the batch: the same engine as the batch
-    assert fam() == 4
     uhd = torch.zeros((2, 2160, 3840, 3), dtype=torch.uint8, device="cuda")
     ctx.pffft_(uhd, 20.0)
-    assert fam() == 4
+    assert fam() == 6
     ctx.pffft_(uhd, 50.0)                                         # 4K, 327 taps: the specialised FFT kernels (4320 / 2560) are faster
     assert fam() == 1
     ctx.pffft_(uhd, 50.0, engine="matrix")
@@ -100,9 +106,31 @@ def test_the_librarys_choice_of_engine(ctx):
     ctx.pffft_(small.clone(), 20.0, engine="matrix")
     assert fam() == 4
     ctx.separable(big, np.array([0.25, 0.5, 0.25], np.float32))
-    assert fam() == 4
+    assert fam() == 6
     ctx.separable(big, np.array([-0.25, 1.5, -0.25], np.float32))  # symmetric, sum 1, negative side taps
-    assert fam() != 4
+    assert fam() not in (4, 6)
+
+
+def test_the_table_cache_tells_pads_and_window_sizes_apart(ctx):
+    """the same taps with pad 8 and then pad 10 (both 1024-point reference lengths for a 1000-pixel side) have different windows,
+    and the two matrix-core engines may use different windows for one pad: neither may pick up the other's fragment table"""
+    torch = _torch()
+    img = torch.from_numpy(_rand_img(1000, 1000, 3)).cuda()
+    taps = np.array([1, 4, 6, 4, 1], np.float32) / 16
+    ref8 = ctx.separable(img.clone(), taps, pad=8, engine="fft").cpu().numpy()
+    ref10 = ctx.separable(img.clone(), taps, pad=10, engine="fft").cpu().numpy()
+    for eng in ("matrix", "fused", "matrix"):
+        a = ctx.separable(img.clone(), taps, pad=8, engine=eng).cpu().numpy()
+        b = ctx.separable(img.clone(), taps, pad=10, engine=eng).cpu().numpy()
+        assert np.abs(a.astype(int) - ref8).max() <= 1 and (a != ref8).mean() < 1e-3
+        assert np.abs(b.astype(int) - ref10).max() <= 1 and (b != ref10).mean() < 1e-3
+    # a clamped window (sigma 20 on a 100 x 100 image: 101 taps, pad 50): 9 window blocks for the two kernels, 11 for the fused one
+    sm = torch.from_numpy(_rand_img(100, 100, 4)).cuda()
+    m1 = ctx.pffft_(sm.clone(), 20.0, engine="matrix")
+    f1 = ctx.pffft_(sm.clone(), 20.0, engine="fused")
+    m2 = ctx.pffft_(sm.clone(), 20.0, engine="matrix")
+    assert torch.equal(m1, m2)
+    assert int((m1.int() - f1.int()).abs().max()) <= 1
 
 
 def test_matrix_engine_extreme_images(ctx):

@@ -123,7 +123,7 @@ def test_batch_equals_single_frames_wave_resident(ctx):
 
 def test_wave_resident_is_the_fft_choice_on_the_metric_frame(ctx):
     """4K sigma 20: among the FFT kernels (engine="fft") the wave-resident family is chosen; switching it off gives the
-    rows-first kernels.  The library's own default is the matrix-core engine.  All three obey the parity contract; they
+    rows-first kernels.  The library's own default is the fused matrix-core kernel.  All of them obey the parity contract; they
     differ from each other only at rounding ties."""
     torch = _torch()
     from oracle import oracle as O
@@ -138,10 +138,13 @@ def test_wave_resident_is_the_fft_choice_on_the_metric_frame(ctx):
     assert_u8_parity(c.cpu().numpy(), want, planes)
     assert (a != c).float().mean().item() < 1e-4
     d = ctx.pffft_(t, 20.0, out=torch.empty_like(t))
-    e = ctx.pffft_(t, 20.0, out=torch.empty_like(t), engine="matrix")
+    e = ctx.pffft_(t, 20.0, out=torch.empty_like(t), engine="fused")
     assert torch.equal(d, e)
     assert_u8_parity(d.cpu().numpy(), want, planes)
     assert (a != d).float().mean().item() < 1e-4
+    m = ctx.pffft_(t, 20.0, out=torch.empty_like(t), engine="matrix")
+    assert_u8_parity(m.cpu().numpy(), want, planes)
+    assert (m != d).float().mean().item() < 1e-4
 
 
 @pytest.mark.parametrize("role,r0", [("col", r) for r in (3, 4, 5, 6, 8, 9, 10)] + [("row", r) for r in (3, 4, 5, 6, 8, 9, 10, 12, 15, 16)])
