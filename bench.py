@@ -38,7 +38,17 @@ os.environ.setdefault("OMP_PROC_BIND", "close")
 os.environ.setdefault("OMP_PLACES", "cores")
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
-ALG_BYTES_PER_PX_KERNEL = 15   # per kernel; 30 B/px for the frame
+MFMA_PEAK_TFLOPS = 2500.0      # MI355X_MICROARCH.md: dense f16 / bf16 MFMA (the 2:1-sparsity figure is not used)
+ALG_BYTES_PER_PX_KERNEL = 15   # per kernel of a two-pass engine; 30 B/px for the frame
+FUSED_BYTES_PER_PX = 6         # what the fused kernel has to move: 3 B/px in + 3 B/px out (+ 3 B/px read by the quirk's pre-pass)
+
+# --config: the BASELINE.json configurations that fit one GPU (rows, cols, sigma, frames per step)
+CONFIGS = {
+    "metric": dict(rows=2160, cols=3840, sigma=20.0, frames=8, label="metric / C4 shard: 3840x2160 RGB u8, sigma=20"),
+    "c2": dict(rows=1080, cols=1920, sigma=20.0, frames=8, label="C2: 1920x1080 RGB u8, sigma=20"),
+    "c3": dict(rows=2160, cols=3840, sigma=50.0, frames=8, label="C3: 3840x2160 RGB u8, sigma=50"),
+    "c5": dict(rows=4320, cols=7680, sigma=20.0, frames=1, label="C5: fastboxblur 7680x4320 RGB u8, 3 passes, k=41"),
+}
 
 
 def native_oracle():
@@ -96,9 +106,32 @@ def baseline_metric():
         return "megapixels/sec Gaussian blur (\u03c3=20, 4K RGB) at 1/2/4/8 GPUs; % HBM roofline"
 
 
-FAMILY_PREFIX = {0: "rowpass_kernel", 1: "fast_", 2: "wr_", 4: "mx_"}
+FAMILY_PREFIX = {0: "rowpass_kernel", 1: "fast_", 2: "wr_", 4: "mx_", 6: "fx_"}
 FAMILY_NAME = {0: "run-time-planned FFT kernels", 1: "specialised rows-first FFT kernels", 2: "wave-resident FFT kernels", 3: "whole-image 2D FFT",
-               4: "matrix-core kernels"}
+               4: "matrix-core kernels (two passes)", 6: "fused matrix-core kernel"}
+DTYPE = {4: "f16 hi+lo operands (u8 pixels exact, taps split in two binary16 halves), f32 accumulate, 24-bit fixed-point intermediate",
+         6: "f16 hi+lo operands (u8 pixels exact, taps and intermediate split in two binary16 halves), f32 accumulate"}
+
+
+def fused_launch_shape(rows, cols, pad, frames, num_cus=256):
+    """what fx_launch_u8 (csrc/fx_kernels.hpp) launches for this call: window blocks, tasks, and the matrix instructions it executes"""
+    nkb = next(n for n in (3, 5, 7, 9, 11) if 8 * (n - 2) >= pad)
+    nt = (nkb - 1) // 2
+    chunks, ntiles = -(-cols // 128), -(-rows // 32)
+    stripes = chunks * frames
+    best = None
+    for n in range(1, -(-ntiles // nt) + 1):
+        t = -(-(-(-ntiles // n)) // nt) * nt
+        ns = -(-ntiles // t)
+        span = -(-stripes * ns // num_cus) * (t + nt)
+        if best is None or span < best[0]:
+            best = (span, ns, t)
+    _, nseg, tps = best
+    steps = sum(min(tps, ntiles - sg * tps) + nt for sg in range(nseg))          # per strip of columns
+    mfma_per_wave_step = 3 * 5 * nkb                                             # 3 channels x (2 row + 3 column products) x window blocks
+    mfmas = stripes * 4 * (steps * mfma_per_wave_step + nseg * 2 * nkb)          # 4 waves per task; the prologue's first row pass
+    return {"nkb": nkb, "tasks": stripes * nseg, "segments_per_strip": nseg, "steps_per_strip": steps, "mfma_instructions": mfmas,
+            "flops": mfmas * 2 * 32 * 32 * 16}
 
 
 def pmc_traffic(role, frames_per_launch, family=2):
@@ -107,11 +140,11 @@ def pmc_traffic(role, frames_per_launch, family=2):
     bytes are None when the summary is missing or was taken with another batching"""
     prefix = FAMILY_PREFIX.get(family, "?")
     default = {"mx_": {"row": "mx_rowpass_u8", "col": "mx_colpass_u8"}, "wr_": {"row": "wr_rowpass_u8", "col": "wr_colpass_u8"},
-               }.get(prefix, {"row": "fast_rowpass3_u8", "col": "fast_colpass_u8"})[role]
+               "fx_": {"blur": "fx_blur_u8"}}.get(prefix, {"row": "fast_rowpass3_u8", "col": "fast_colpass_u8"})[role]
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         t = json.load(open(path))
-        name = [k for k in t if role + "pass" in k and k.startswith(prefix)][0]
+        name = [k for k in t if (role + "pass" in k or (prefix == "fx_" and "fx_blur" in k)) and k.startswith(prefix)][0]
         e = t[name]
         if abs(e["frames_per_launch"] - frames_per_launch) > 1e-9:
             return name, None
@@ -155,21 +188,48 @@ def percentiles(ms):
     return {"median": round(q(0.5), 4), "p10": round(q(0.1), 4), "p90": round(q(0.9), 4)}
 
 
-def copy_bandwidth(torch, dev, mib=1024, reps=5):
-    """the box's streaming-copy rate in GB/s (bytes read + bytes written), beside the 8 TB/s spec figure"""
-    n = mib << 20
-    a = torch.empty(n, dtype=torch.uint8, device=dev)
-    b = torch.empty(n, dtype=torch.uint8, device=dev)
-    a.zero_()
-    b.copy_(a)
+def copy_bandwidth(ctx, mib=1024, reps=5):
+    """the box's streaming rate in GB/s (bytes read + bytes written) for the library's own 16-byte-per-lane copy kernel
+    (blur_copy_bandwidth), beside the 8 TB/s spec figure; MI355X_MICROARCH.md gives 6.29 TB/s for this access shape"""
+    return ctx.copy_bandwidth(mib, reps)
+
+
+def box_config(args, torch, B):
+    """BASELINE config 5: fastboxblur (call site Source.cpp:587), 8K RGB u8, box width 41, 3 passes, in place, device-resident"""
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctx = B.BlurContext(0)
+    c = CONFIGS["c5"]
+    rows, cols, k, passes = c["rows"], c["cols"], 41, 3
+    g = torch.Generator(device=dev)
+    g.manual_seed(0x5EED0005)
+    img = torch.randint(0, 256, (rows, cols, 3), dtype=torch.uint8, device=dev, generator=g)
+    for _ in range(max(args.warmup, 3)):
+        ctx.fastboxblur(img, k, passes)
     torch.cuda.synchronize(dev)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        b.copy_(a)
-    e1.record()
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    marks[0].record()
+    for i in range(args.steps):
+        ctx.fastboxblur(img, k, passes)
+        marks[i + 1].record()
     torch.cuda.synchronize(dev)
-    return 2.0 * n * reps / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    dt = time.perf_counter() - t0
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    px = rows * cols
+    alg = 12 * passes * px
+    ms = 1e3 * dt / args.steps
+    achieved = alg / (ms * 1e-3) / 1e9
+    rec = {"metric": "megapixels/sec fastboxblur (8K RGB, 3-pass box k=41) at 1 GPU; % HBM roofline", "value": round(args.steps * px / 1e6 / dt, 1), "unit": "megapixels/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u8 (16-bit running sums)", "data": "synthetic",
+           "config": {"workload": c["label"] + ", in place, device-resident", "frames_per_gpu": 1},
+           "ms_per_step_gpu": percentiles(per_step),
+           "roofline": {"bound": "hbm", "kernel": "boxrow4_kernel + 3 x boxcol4_kernel (whole call)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": alg}}
+    if not args.no_copy:
+        rec["roofline"]["copy_peak"] = round(copy_bandwidth(ctx), 1)
+    print(json.dumps(rec), flush=True)
 
 
 def reference_sweep(args, torch, B):
@@ -232,10 +292,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=8, help="frames per GPU per step (BASELINE C4: 64 frames over 8 GPUs)")
-    ap.add_argument("--rows", type=int, default=2160)
-    ap.add_argument("--cols", type=int, default=3840)
-    ap.add_argument("--sigma", type=float, default=20.0)
+    ap.add_argument("--frames", type=int, default=None, help="frames per GPU per step (default 8; BASELINE C4: 64 frames over 8 GPUs)")
+    ap.add_argument("--config", default="metric", choices=sorted(CONFIGS), help="which BASELINE.json configuration (metric = the headline one; "
+                    "c2 1080p sigma 20, c3 4K sigma 50, c5 fastboxblur 8K): sets --rows / --cols / --sigma / --frames unless given")
+    ap.add_argument("--rows", type=int, default=None)
+    ap.add_argument("--cols", type=int, default=None)
+    ap.add_argument("--sigma", type=float, default=None)
     ap.add_argument("--col-group", type=int, default=0)
     ap.add_argument("--frames-per-launch", type=int, default=0, help="0 = the library's choice")
     ap.add_argument("--data", default="synthetic", choices=["synthetic", "natural"],
@@ -243,8 +305,8 @@ def main():
                          "reference's test_images tiled to the frame size")
     ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the N>1 path on one GPU)")
     ap.add_argument("--all-on-device0", action="store_true", help="rehearsal: every rank uses cuda:0")
-    ap.add_argument("--engine", default="auto", choices=["auto", "matrix", "fft", "wave-resident", "rows-first"],
-                    help="auto: the library's choice (the matrix-core kernels where one exists for the kernel width); the others force a family")
+    ap.add_argument("--engine", default="auto", choices=["auto", "fused", "matrix", "fft", "wave-resident", "rows-first"],
+                    help="auto: the library's choice (the fused matrix-core kernel where it applies); the others force an engine / FFT family")
     ap.add_argument("--wave-resident", default="auto", choices=["auto", "on", "off"],
                     help="A/B: the wave-resident kernels (columns first, N = 256 R0) or the rows-first kernels of round 1")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -259,6 +321,10 @@ def main():
                          "sigma = sqrt(longer side), one image per call; prints one JSON line with a row per size")
     ap.add_argument("--rehearse", action="store_true", help="no GPU work: the step is a sleep (launch / reduce / report path on a CPU-only box)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    for k in ("rows", "cols", "sigma", "frames"):
+        if getattr(args, k) is None:
+            setattr(args, k, cfg[k])
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args, sys.argv[1:])          # does not return
 
@@ -304,6 +370,8 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.preset == "reference-sweep":
         return reference_sweep(args, torch, B)
+    if args.config == "c5":
+        return box_config(args, torch, B)
     if args.all_on_device0:
         local = 0
     if local >= torch.cuda.device_count():
@@ -386,7 +454,7 @@ def main():
         fft_elapsed, _, _ = timed_run(frames, fsteps, 2, False, engine="fft")
         fft_value = world * fsteps * F * rows * cols / 1e6 / fft_elapsed
         timed_run(frames, 1, 0, False)                      # leave the context on the default engine (last_family below)
-    copy_gbs = None if (args.no_copy or rank != 0) else copy_bandwidth(torch, dev)
+    copy_gbs = None if (args.no_copy or rank != 0) else copy_bandwidth(ctx)
 
     if rank == 0:
         px = rows * cols
@@ -407,6 +475,11 @@ def main():
             engine = ("%s: both passes as banded Toeplitz products on v_mfma_f32_32x32x16_f16 (window %d positions for %d taps, taps and "
                       "intermediate in hi + lo binary16 halves, f32 accumulation), Nyquist-slot quirk as rank-one terms"
                       % (FAMILY_NAME[family], 16 * nkb, sz["kSize"]))
+        elif family == 6:
+            shape = fused_launch_shape(rows, cols, sz["pad"], F)
+            engine = ("%s: row pass, register hand-off, column pass and byte emission in one launch on v_mfma_f32_32x32x16_f16 (window %d positions "
+                      "for %d taps; taps and intermediate in hi + lo binary16 halves, f32 accumulation; no intermediate in memory), Nyquist-slot quirk as "
+                      "rank-one terms from an integer pre-pass over the image" % (FAMILY_NAME[family], 16 * shape["nkb"], sz["kSize"]))
         else:
             engine = FAMILY_NAME.get(family, "?") + " at the reference's FFT lengths"
         rec = {
@@ -420,11 +493,12 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": DTYPE.get(family, "f32"),
             "data": args.data,
             "config": {
-                "workload": "%dx%d RGB u8 frames, sigma=%g (kSize %d), reference FFT row/col lengths %d/%d, %d frames per GPU per step, device-resident"
-                            % (cols, rows, sigma, sz["kSize"], sz["N1"], sz["N0"], F),
+                "workload": "%s: %dx%d RGB u8 frames, sigma=%g (kSize %d), reference FFT row/col lengths %d/%d, %d frames per GPU per step, device-resident"
+                            % (cfg["label"] if (rows, cols, sigma) == (cfg["rows"], cfg["cols"], cfg["sigma"]) else "custom", cols, rows, sigma, sz["kSize"],
+                               sz["N1"], sz["N0"], F),
                 "engine": engine,
                 "frames_per_gpu": F,
                 "sharding": "frames over ranks, no data-path collective",
@@ -437,8 +511,35 @@ def main():
         if fft_value is not None:
             rec["value_fft_kernels"] = round(fft_value, 1)           # same workload, --engine fft (wave-resident FFT kernels)
         frame_bytes = 2 * ALG_BYTES_PER_PX_KERNEL * px
+        # the metric's "% HBM roofline" as BASELINE.md section 3 defines it: 30 algorithmic B/px of the two-pass algorithm / whole-job time / 8 TB/s
         rec["frame_roofline_frac"] = round((world * args.steps * F * frame_bytes / elapsed / 1e9) / (HBM_PEAK_GBS * world), 4)
-        if tm and tm["row_launches"] and tm["col_launches"]:
+        if family == 6 and tm and tm["row_launches"]:
+            # One launch does both passes and keeps the intermediate on chip: the kernel is bound by the matrix pipe, not by HBM.
+            # achieved = the matrix instructions the launch executes x 32768 flop / its average duration (HIP events on the launch
+            # stream inside the timed region); the HBM side is reported with what the kernel has to move (6 B/px).
+            k_ms = tm["row_ms"] / tm["row_launches"]
+            fpl = tm["row_frames"] / tm["row_launches"]
+            shape = fused_launch_shape(rows, cols, sz["pad"], int(round(fpl)))
+            name = "fx_blur_u8<%d, %s>" % (shape["nkb"], "true")
+            achieved = shape["flops"] / (k_ms * 1e-3) / 1e12
+            name2, traffic = pmc_traffic("blur", fpl, family)
+            side_ms = tm["col_ms"] / max(args.steps, 1)                # per step: edge strips + the quirk's pre-pass and term kernels
+            hbm_alg = FUSED_BYTES_PER_PX * px * fpl
+            rec["roofline"] = {
+                "bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "avg_launch_ms": {name: round(k_ms, 4), "side kernels per step (fx_edge_strips, fx_altsums, fx_quirk_reduce, fx_quirk_cols)": round(side_ms, 4)},
+                "frames_per_launch": fpl,
+                "flops_per_launch": shape["flops"], "mfma_instructions_per_launch": shape["mfma_instructions"], "tasks": shape["tasks"],
+                "useful_flop_frac": round((2 * sz["pad"] + 1) / (16.0 * shape["nkb"]), 4),     # taps / window positions the products cover
+                "hbm": {"alg_bytes_per_launch": hbm_alg, "achieved": round(hbm_alg / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(hbm_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "two_pass_alg_bytes_per_launch": 2 * ALG_BYTES_PER_PX_KERNEL * px * fpl,
+                        "two_pass_frac": round(2 * ALG_BYTES_PER_PX_KERNEL * px * fpl / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            }
+            if copy_gbs:
+                rec["roofline"]["hbm"]["copy_peak"] = round(copy_gbs, 1)
+        elif tm and tm["row_launches"] and tm["col_launches"]:
             row_ms = tm["row_ms"] / tm["row_launches"]
             col_ms = tm["col_ms"] / tm["col_launches"]
             fpl = tm["row_frames"] / tm["row_launches"]            # frames one launch covers

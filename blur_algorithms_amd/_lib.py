@@ -78,6 +78,7 @@ SYMBOLS = {
     "blur_free": (C.c_int, [_P, _P]),
     "blur_host_alloc": (C.c_int, [_P, C.POINTER(_P), C.c_size_t]),
     "blur_host_free": (C.c_int, [_P, _P]),
+    "blur_copy_bandwidth": (C.c_int, [_P, C.c_size_t, C.c_int, C.POINTER(C.c_double)]),
     "blur_memcpy_h2d": (C.c_int, [_P, _P, _P, C.c_size_t]),
     "blur_memcpy_d2h": (C.c_int, [_P, _P, _P, C.c_size_t]),
 }

@@ -162,6 +162,12 @@ class BlurContext:
         fn.restype = C.c_int
         return int(fn(self._h))
 
+    def copy_bandwidth(self, mib=1024, reps=5):
+        """GB/s (read + written) of a 16-byte-per-lane device copy of `mib` MiB: the box's streaming rate for the kernels' access shape"""
+        g = C.c_double(0)
+        self._check(self._lib.blur_copy_bandwidth(self._h, int(mib) << 20, int(reps), C.byref(g)))
+        return g.value
+
     def timing_enable(self, on=True):
         self._check(self._lib.blur_ctx_timing_enable(self._h, 1 if on else 0))
 

@@ -576,6 +576,12 @@ __global__ __launch_bounds__(256) void img2d_logspec_kernel(const float2* __rest
     }
 }
 
+// 16 bytes per lane, grid-stride: the access shape of the engines' wide loads and stores (blur_copy_bandwidth)
+__global__ __launch_bounds__(256) void copy16_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16)
+{
+    for (size_t i = blockIdx.x * 256ull + threadIdx.x; i < n16; i += static_cast<size_t>(gridDim.x) * 256ull) dst[i] = src[i];
+}
+
 // Reflect_101<uint8_t, C> (Utils.hpp:212-243) as a piece: out[(rows+top+bottom) x (cols+left+right) x C]
 __global__ __launch_bounds__(256) void reflect101_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int rows, int cols, int C,
                                                             int top, int left, int out_rows, int out_cols)
@@ -1538,7 +1544,7 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
             ctx->fx_strips_bytes = bytes;
         }
         TimedLaunch t(ctx, 1, 0);
-        hipLaunchKernelGGL(fx_edge_strips, dim3((rows * (win / 4) + 255) / 256, nstrips, nframes), dim3(256), 0, ctx->stream, d_src, ctx->fx_strips, rows, cols, pada, chunks,
+        hipLaunchKernelGGL(fx_edge_strips, dim3((((rows + 3) / 4) * (win / 4) + 255) / 256, nstrips, nframes), dim3(256), 0, ctx->stream, d_src, ctx->fx_strips, rows, cols, pada, chunks,
                            g.nright);
         HIP_TRY(ctx, hipGetLastError());
     }
@@ -2302,6 +2308,35 @@ int blur_memcpy_d2h(blur_ctx* ctx, void* dst, const void* d_src, size_t bytes)
     if (!ctx) return BLUR_ERR_INVALID;
     HIP_TRY(ctx, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return BLUR_OK;
+}
+
+int blur_copy_bandwidth(blur_ctx* ctx, size_t bytes, int reps, double* gbs)
+{
+    if (!ctx || !gbs || reps <= 0 || bytes < 4096) return BLUR_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const size_t n16 = bytes / 16;
+    uint4 *a = nullptr, *b = nullptr;
+    HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&a), n16 * 16));
+    if (hipMalloc(reinterpret_cast<void**>(&b), n16 * 16) != hipSuccess) { (void)hipFree(a); return fail(ctx, BLUR_ERR_NOMEM, "blur_copy_bandwidth: out of device memory"); }
+    (void)hipMemsetAsync(a, 0x5a, n16 * 16, ctx->stream);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    const int grid = ctx->num_cus * 8;
+    hipLaunchKernelGGL(copy16_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, b, n16);
+    (void)hipEventRecord(e0, ctx->stream);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(copy16_kernel, dim3(grid), dim3(256), 0, ctx->stream, a, b, n16);
+    (void)hipEventRecord(e1, ctx->stream);
+    hipError_t err = hipEventSynchronize(e1);
+    float ms = 0.f;
+    if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    (void)hipFree(a);
+    (void)hipFree(b);
+    if (err != hipSuccess || !(ms > 0.f)) return fail(ctx, BLUR_ERR_HIP, "blur_copy_bandwidth: timing failed");
+    *gbs = 2.0 * static_cast<double>(n16) * 16.0 * reps / (ms * 1e-3) / 1e9;
     return BLUR_OK;
 }
 

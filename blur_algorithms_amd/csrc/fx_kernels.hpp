@@ -547,40 +547,52 @@ inline int fx_right_strips(int cols, int pada)
 // (beyond one reflection, which only zero taps read: whatever the clamped load returns).  A thread moves one group of 4 pixels: the
 // image width is a multiple of 4 and so is x0 - pada, so a group lies inside the image (one aligned 12-byte load) or is the
 // pixel-reversed copy of 4 adjacent image pixels (one unaligned 12-byte load, three v_perm_b32).
-// grid (blocks over rows x win / 4 groups, strips, frames)
+// grid (blocks over ceil(rows / 4) x win / 4 threads: 4 rows of one group each, strips, frames)
 __global__ __launch_bounds__(256) void fx_edge_strips(const uint8_t* __restrict__ src, uint8_t* __restrict__ strips, int rows, int cols, int pada, int chunks, int nright)
 {
     const int win = kFxChunk + 2 * pada, gpr = win / 4, f = blockIdx.z, sidx = blockIdx.y;
     const int xc = sidx == 0 ? 0 : chunks - nright + sidx - 1, x0 = kFxChunk * xc;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= rows * gpr) return;
-    const int r = i / gpr, gidx = i - r * gpr;
+    const int i = blockIdx.x * 256 + threadIdx.x, rq = (rows + 3) / 4;
+    if (i >= rq * gpr) return;
+    const int r4 = i / gpr, gidx = i - r4 * gpr;
     const int X = x0 - pada + 4 * gidx;
     const bool mir = X < 0 || X >= cols;
     const int xs = X < 0 ? -X - 3 : (X >= cols ? 2 * cols - 5 - X : X);
-    const uint8_t* line = src + (static_cast<size_t>(f) * rows + r) * cols * 3;
+    const bool fast = xs >= 0 && xs + 3 < cols;
     typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-    u3 o;
-    if (xs >= 0 && xs + 3 < cols) {
-        const u3 d = *reinterpret_cast<const u3*>(line + 3 * xs);
-        o = d;
-        if (mir) {       // pixels 3, 2, 1, 0 of the loaded four: bytes [9 10 11 6] [7 8 3 4] [5 0 1 2]
-            o[0] = __builtin_amdgcn_perm(d[2], d[1], 0x02070605u);
-            o[1] = (d[1] >> 24) | ((d[2] & 0xffu) << 8) | ((d[0] >> 24) << 16) | ((d[1] & 0xffu) << 24);
-            o[2] = __builtin_amdgcn_perm(d[1], d[0], 0x02010005u);
-        }
-    } else {             // reaches past one reflection (tiny images): pixel by pixel
-        uint32_t b[12];
+    const uint8_t* img = src + static_cast<size_t>(f) * rows * cols * 3;
+    uint8_t* sbase = strips + (static_cast<size_t>(f) * (1 + nright) + sidx) * rows * (3 * win) + 12 * gidx;
+    u3 d[4];
+    if (fast) {
 #pragma unroll
-        for (int qd = 0; qd < 4; ++qd) {
-            const uint8_t* px = line + 3 * mx_refl(X + qd, cols);
-            b[3 * qd] = px[0]; b[3 * qd + 1] = px[1]; b[3 * qd + 2] = px[2];
-        }
-        o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
-        o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
-        o[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+        for (int k = 0; k < 4; ++k) d[k] = *reinterpret_cast<const u3*>(img + (static_cast<size_t>(min(4 * r4 + k, rows - 1)) * cols + xs) * 3);
     }
-    *reinterpret_cast<u3*>(strips + ((static_cast<size_t>(f) * (1 + nright) + sidx) * rows + r) * (3 * win) + 12 * gidx) = o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = 4 * r4 + k;
+        if (r >= rows) break;
+        u3 o;
+        if (fast) {
+            o = d[k];
+            if (mir) {       // pixels 3, 2, 1, 0 of the loaded four: bytes [9 10 11 6] [7 8 3 4] [5 0 1 2]
+                o[0] = __builtin_amdgcn_perm(d[k][2], d[k][1], 0x02070605u);
+                o[1] = (d[k][1] >> 24) | ((d[k][2] & 0xffu) << 8) | ((d[k][0] >> 24) << 16) | ((d[k][1] & 0xffu) << 24);
+                o[2] = __builtin_amdgcn_perm(d[k][1], d[k][0], 0x02010005u);
+            }
+        } else {             // reaches past one reflection (tiny images): pixel by pixel
+            const uint8_t* line = img + static_cast<size_t>(r) * cols * 3;
+            uint32_t b[12];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const uint8_t* px = line + 3 * mx_refl(X + qd, cols);
+                b[3 * qd] = px[0]; b[3 * qd + 1] = px[1]; b[3 * qd + 2] = px[2];
+            }
+            o[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+            o[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+            o[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+        }
+        *reinterpret_cast<u3*>(sbase + static_cast<size_t>(r) * (3 * win)) = o;
+    }
 }
 
 constexpr int kFxSumRows = 32;          // image rows per band (packed 16-bit column sums: 32 x 3 x 255 < 65536)
@@ -603,13 +615,16 @@ __device__ __forceinline__ int fx_row16_sum(int v)
 __global__ __launch_bounds__(256) void fx_altsums(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
                                                   int rows, int cols, int pad, int nbands, int nbatches)
 {
-    __shared__ int sred[kFxSumRows][3][16];        // per row and channel: the 16 row-of-16-lanes sums of the workgroup (no atomics:
-                                                   // the compiler turns a same-address LDS atomic into a serial loop over the lanes)
+    __shared__ int sred[kFxSumRows][3][16];        // per row and channel: 16 slots, lane l of every wave adds into slot l & 15 (one
+                                                   // ds_add_u32 per value: a same-address atomic the compiler would turn into a serial
+                                                   // loop over the lanes, and a DPP reduction costs twelve dependent instructions)
     const int f = blockIdx.z, batch = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
     const uint8_t* img = src + static_cast<size_t>(f) * rows * cols * 3;
     const int groups = cols / 4, r0 = band * kFxSumRows, r1 = min(r0 + kFxSumRows, rows);
     const int gi = batch * 256 + tid, x = 4 * gi;
     const bool act = gi < groups;
+    for (int i = tid; i < kFxSumRows * 3 * 16; i += 256) (&sred[0][0][0])[i] = 0;
+    __syncthreads();
     const int flip = (pad & 1) ? -1 : 1;
     const bool plain = x > pad && x + 3 < cols - 1 - pad;                 // no pixel of the group is mirrored: weights +-1 by parity
     int wq[4];
@@ -656,15 +671,13 @@ __global__ __launch_bounds__(256) void fx_altsums(const uint8_t* __restrict__ sr
                         }
                 }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int t = fx_row16_sum(act ? s[c] : 0);
-                    if ((tid & 15) == 0) sred[r - r0][c][tid >> 4] = t;
-                }
+                for (int c = 0; c < 3; ++c) atomicAdd(&sred[r - r0][c][tid & 15], act ? s[c] : 0);
                 // column sums: bytes 0, 2 of each dword in one packed pair, bytes 1, 3 in the other; |wy| = 1, 2 or 3 (uniform)
                 const uint32_t aw = static_cast<uint32_t>(wy < 0 ? -wy : wy);
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
-                    const uint32_t lo = (d[i][j] & 0x00ff00ffu) * aw, hi = ((d[i][j] >> 8) & 0x00ff00ffu) * aw;
+                    uint32_t lo = __builtin_amdgcn_perm(0u, d[i][j], 0x0c020c00u), hi = __builtin_amdgcn_perm(0u, d[i][j], 0x0c030c01u);     // bytes 0, 2 | 1, 3
+                    if (aw != 1) { lo *= aw; hi *= aw; }                      // (uniform: the mirrored rows only)
                     if (wy > 0) { accp[2 * j] += lo; accp[2 * j + 1] += hi; }
                     else { accn[2 * j] += lo; accn[2 * j + 1] += hi; }
                 }
@@ -759,11 +772,15 @@ __global__ __launch_bounds__(256) void fx_quirk_cols(const int* __restrict__ cco
     extern __shared__ __attribute__((aligned(16))) unsigned char fxq_lds[];
     const int f = blockIdx.y, tid = threadIdx.x;
     const int e0 = blockIdx.x * 256;
-    // pixels whose column sums this block's outputs read: [xa, xb] inside the image (reflect-101 maps into it)
-    const int xa = max(0, e0 / 3 - pad), xb = min(cols - 1, (e0 + 255) / 3 + pad), nval = 3 * (xb - xa + 1);
+    // the tile: Ccol at the pixels xa .. xb = the block's pixels with the taps' reach on both sides, reflect-101 applied when it is
+    // filled, so the convolution loop is a plain dot product
+    const int xa = e0 / 3 - pad, xb = (e0 + 255) / 3 + pad, nval = 3 * (xb - xa + 1);
     int* cc = reinterpret_cast<int*>(fxq_lds);
     float* tp = reinterpret_cast<float*>(fxq_lds) + tileints;
-    for (int i = tid; i < nval; i += 256) cc[i] = ccol[static_cast<size_t>(f) * 3 * cols + 3 * xa + i];
+    for (int i = tid; i < nval; i += 256) {
+        const int xx = mx_refl(xa + i / 3, cols);
+        cc[i] = ccol[static_cast<size_t>(f) * 3 * cols + 3 * xx + i % 3];
+    }
     for (int i = tid; i < 2 * pad + 1; i += 256) tp[i] = taps[i];
     __syncthreads();
     const int e = e0 + tid;
@@ -771,13 +788,14 @@ __global__ __launch_bounds__(256) void fx_quirk_cols(const int* __restrict__ cco
     const int x = e / 3, c = e - 3 * x;
     float out = 0.f;
     if (x < cols) {
+        const int* ccx = cc + 3 * (x - pad - xa) + c;              // tap t = -pad sits here
         double acc[4] = { 0, 0, 0, 0 };
-        int t = -pad;
-        for (; t + 4 <= pad + 1; t += 4) {
+        int t = 0;
+        for (; t + 4 <= 2 * pad + 1; t += 4) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += static_cast<double>(tp[t + j + pad]) * cc[3 * (mx_refl(x + t + j, cols) - xa) + c];
+            for (int j = 0; j < 4; ++j) acc[j] += static_cast<double>(tp[t + j]) * ccx[3 * (t + j)];
         }
-        for (; t <= pad; ++t) acc[0] += static_cast<double>(tp[t + pad]) * cc[3 * (mx_refl(x + t, cols) - xa) + c];
+        for (; t <= 2 * pad; ++t) acc[0] += static_cast<double>(tp[t]) * ccx[3 * t];
         const double sp = (pad & 1) ? -1.0 : 1.0, sx = ((x + pad) & 1) ? -1.0 : 1.0;
         out = static_cast<float>(static_cast<double>(dc) * sp * (((acc[0] + acc[1]) + (acc[2] + acc[3])) + static_cast<double>(dr) * sx * zsum[static_cast<size_t>(f) * 3 + c]));
     }

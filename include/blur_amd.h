@@ -278,6 +278,11 @@ int blur_memcpy_d2h(blur_ctx* ctx, void* dst, const void* d_src, size_t bytes); 
 int blur_host_alloc(blur_ctx* ctx, void** h_ptr, size_t bytes);
 int blur_host_free(blur_ctx* ctx, void* h_ptr);
 
+/* ---- measurement: the box's streaming rate as THIS library's kernels would see it: a 16-byte-per-lane copy of `bytes` bytes
+   (device to device, `reps` launches between two events on the context's stream); *gbs = (bytes read + bytes written) / s / 1e9.
+   bench.py prints it beside the 8 TB/s spec figure (MI355X_MICROARCH.md gives 6.29 TB/s for this access shape). */
+int blur_copy_bandwidth(blur_ctx* ctx, size_t bytes, int reps, double* gbs);
+
 #ifdef __cplusplus
 }
 #endif

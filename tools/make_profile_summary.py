@@ -32,7 +32,7 @@ def mean_counters(sub):
     for f in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            m = re.search(r"((?:fast|wr|mx)_(?:row|col)pass\d*_u8|mx_altsums_reduce|mx_altsums|mx_quirk_terms)", k)
+            m = re.search(r"((?:fast|wr|mx)_(?:row|col)pass\d*_u8|mx_altsums_reduce|mx_altsums|mx_quirk_terms|fx_blur_u8|fx_altsums|fx_edge_strips|fx_quirk_reduce|fx_quirk_cols)", k)
             name = m.group(1) if m else None
             if name:
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
@@ -42,7 +42,7 @@ def mean_counters(sub):
 summary = {}
 # SQ counter summary (VALU / LDS busy, bank conflicts, wait and issue-stall cycles) beside the traffic counters
 sq = {}
-for sub in ("sq_a", "sq_b", "sq_c"):
+for sub in ("sq_a", "sq_b", "sq_c", "sq_d"):
     m, n = mean_counters(sub)
     for k in m:
         sq.setdefault(k, {}).update({c: round(v, 1) for c, v in m[k].items()})
@@ -54,6 +54,10 @@ for k, d in sq.items():
                         ("valu_active_frac", "SQ_ACTIVE_INST_VALU"), ("lds_active_frac", "SQ_ACTIVE_INST_LDS")):
             if c in d:
                 d[name] = round(d[c] / wc, 4)
+        # SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per v_mfma_f32_32x32x16_f16), SQ_WAVE_CYCLES quad-cycles summed over the waves;
+        # with one wave per SIMD (the fused kernel) the quotient is the fraction of the kernel the matrix pipe is busy
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in d:
+            d["mfma_busy_frac_one_wave_per_simd"] = round(d["SQ_VALU_MFMA_BUSY_CYCLES"] / (4.0 * wc), 4)
     if d.get("SQ_LDS_IDX_ACTIVE"):
         d["lds_bank_conflict_frac"] = round(d.get("SQ_LDS_BANK_CONFLICT", 0.0) / d["SQ_LDS_IDX_ACTIVE"], 4)
 if sq:
@@ -76,7 +80,7 @@ for k in sorted(summary):
     # on their known input sizes -- FETCH_SIZE reads 99.97 MB for the 199.07 MB of u8 frames and 402.6 MB for the 796-800 MB
     # of float intermediate, i.e. one half in both cases, like the wide reads: f = 2
     f = 1.0 if k == "fast_rowpass_u8" else 2.0
-    if not k.endswith("pass_u8") and not k.endswith("pass3_u8"):
+    if not k.endswith("pass_u8") and not k.endswith("pass3_u8") and not k.startswith("fx_"):
         continue                                       # the quirk's small kernels: counters kept in *_pmc_counters.json only
     if "FETCH_SIZE" in summary[k] and "WRITE_SIZE" in summary[k]:
         fetch, write = summary[k]["FETCH_SIZE"] * 1024, summary[k]["WRITE_SIZE"] * 1024
@@ -84,7 +88,8 @@ for k in sorted(summary):
             "frames_per_launch": frames_per_launch,
             "fetch_size_raw_bytes": fetch, "fetch_correction": f, "write_size_bytes": write,
             "hbm_bytes_per_launch": fetch * f + write,
-            "alg_bytes_per_launch": 15 * px * frames_per_launch,
+            # two-pass kernels: 15 B/px each; the fused kernel has to move 6 B/px (3 in + 3 out), its pre-pass 3 B/px
+            "alg_bytes_per_launch": ({"fx_blur_u8": 6, "fx_altsums": 3}.get(k, 15) * px * frames_per_launch) if not k.startswith("fx_") or k in ("fx_blur_u8", "fx_altsums") else None,
             "l2_hit_rate": round(summary[k]["TCC_HIT_sum"] / (summary[k]["TCC_HIT_sum"] + summary[k]["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in summary[k] else None,
             "source": "%s_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, separate runs of bench.py)" % tag,
         }
