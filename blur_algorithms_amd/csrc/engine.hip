@@ -1536,19 +1536,22 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     if (!g.aligned) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: frame pointers must be 4-byte aligned");
     const int qrows = 32 * (g.ntiles + nt), qpitch = (3 * cols + 31) & ~31;
     {   // the edge chunks' windows
-        const int win = kFxChunk + 2 * pada, nstrips = 1 + g.nright, chunks = (cols + kFxChunk - 1) / kFxChunk;
+        const int win = kFxChunk + 2 * pada, nstrips = 1 + g.nright;
         const size_t bytes = static_cast<size_t>(nframes) * nstrips * rows * win * 3 + 64;
         if (ctx->fx_strips_bytes < bytes) {
             if (ctx->fx_strips) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->fx_strips)); ctx->fx_strips = nullptr; ctx->fx_strips_bytes = 0; }
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->fx_strips), bytes));
             ctx->fx_strips_bytes = bytes;
         }
-        TimedLaunch t(ctx, 1, 0);
-        hipLaunchKernelGGL(fx_edge_strips, dim3((((rows + 3) / 4) * (win / 4) + 255) / 256, nstrips, nframes), dim3(256), 0, ctx->stream, d_src, ctx->fx_strips, rows, cols, pada, chunks,
-                           g.nright);
-        HIP_TRY(ctx, hipGetLastError());
     }
     float *qrow = nullptr, *qcol = nullptr;
+    const int strip_blocks = (((rows + 3) / 4) * ((kFxChunk + 2 * pada) / 4) + 255) / 256, chunks_x = (cols + kFxChunk - 1) / kFxChunk;
+    if (!p.mx_quirk) {
+        TimedLaunch t(ctx, 1, nframes);
+        hipLaunchKernelGGL(fx_prepass, dim3(strip_blocks * (1 + g.nright) * nframes), dim3(256), 0, ctx->stream, d_src, nullptr, nullptr, nullptr, ctx->fx_strips, rows, cols,
+                           p.sz.pad, pada, 1, 1, 0, chunks_x, g.nright, strip_blocks);
+        HIP_TRY(ctx, hipGetLastError());
+    }
     if (p.mx_quirk) {
         // scratch per frame: ints: srow_part [batches][rows][3], cpart [bands][3 cols], ccol [3 cols]; 64-bit: zpart [bands][batches][3];
         // floats: qrow [3][qrows], qcol [qpitch]
@@ -1576,7 +1579,9 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         qrow = ctx->mx_terms;
         qcol = qrow + static_cast<size_t>(3) * qrows * nframes;
         { TimedLaunch t(ctx, 1, nframes);
-          hipLaunchKernelGGL(fx_altsums, dim3(nbands, nbatches, nframes), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, rows, cols, p.sz.pad, nbands, nbatches);
+          const int n_alt = nbands * nbatches * nframes;
+          hipLaunchKernelGGL(fx_prepass, dim3(n_alt + strip_blocks * (1 + g.nright) * nframes), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, ctx->fx_strips, rows, cols,
+                             p.sz.pad, pada, nbands, nbatches, n_alt, chunks_x, g.nright, strip_blocks);
           HIP_TRY(ctx, hipGetLastError());
           const int nrb = (qrows + 255) / 256, nvb = (3 * cols + 255) / 256, ncb = (qpitch + 255) / 256;
           hipLaunchKernelGGL(fx_quirk_reduce, dim3(nrb + nvb + 1, nframes), dim3(256), 0, ctx->stream, srow, cpart, zpart, qrow, ccol, zsum, rows, cols, p.sz.pad, pada,

@@ -547,12 +547,13 @@ inline int fx_right_strips(int cols, int pada)
 // (beyond one reflection, which only zero taps read: whatever the clamped load returns).  A thread moves one group of 4 pixels: the
 // image width is a multiple of 4 and so is x0 - pada, so a group lies inside the image (one aligned 12-byte load) or is the
 // pixel-reversed copy of 4 adjacent image pixels (one unaligned 12-byte load, three v_perm_b32).
-// grid (blocks over ceil(rows / 4) x win / 4 threads: 4 rows of one group each, strips, frames)
-__global__ __launch_bounds__(256) void fx_edge_strips(const uint8_t* __restrict__ src, uint8_t* __restrict__ strips, int rows, int cols, int pada, int chunks, int nright)
+// work items (fx_prepass): blocks over ceil(rows / 4) x win / 4 threads (4 rows of one group each) x strips x frames
+__device__ __forceinline__ void fx_edge_strips_body(const uint8_t* __restrict__ src, uint8_t* __restrict__ strips, int rows, int cols, int pada, int chunks, int nright,
+                                                    int bx, int sidx, int f)
 {
-    const int win = kFxChunk + 2 * pada, gpr = win / 4, f = blockIdx.z, sidx = blockIdx.y;
+    const int win = kFxChunk + 2 * pada, gpr = win / 4;
     const int xc = sidx == 0 ? 0 : chunks - nright + sidx - 1, x0 = kFxChunk * xc;
-    const int i = blockIdx.x * 256 + threadIdx.x, rq = (rows + 3) / 4;
+    const int i = bx * 256 + threadIdx.x, rq = (rows + 3) / 4;
     if (i >= rq * gpr) return;
     const int r4 = i / gpr, gidx = i - r4 * gpr;
     const int X = x0 - pada + 4 * gidx;
@@ -612,18 +613,17 @@ __device__ __forceinline__ int fx_row16_sum(int v)
 //   srow_part[f][batch][r][c]  sum over the batch's pixels of wx(x) img[r][x][c]
 //   cpart[f][band][3 x + c]    sum over the band's rows of wy(r) img[r][x][c]
 //   zpart[f][band][batch][c]   sum over the band's rows of wy(r) srow_part[f][batch][r][c]       (the parts of Z)
-__global__ __launch_bounds__(256) void fx_altsums(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
-                                                  int rows, int cols, int pad, int nbands, int nbatches)
+// sred[row][channel][lane]: lane l of every wave adds into slot l (one conflict-free ds_add_u32 per value: a same-address atomic the
+// compiler would turn into a serial loop over the lanes, and a DPP reduction costs twelve dependent instructions)
+__device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
+                                                int rows, int cols, int pad, int nbands, int nbatches, int band, int batch, int f, int (*sred)[3][64])
 {
-    __shared__ int sred[kFxSumRows][3][16];        // per row and channel: 16 slots, lane l of every wave adds into slot l & 15 (one
-                                                   // ds_add_u32 per value: a same-address atomic the compiler would turn into a serial
-                                                   // loop over the lanes, and a DPP reduction costs twelve dependent instructions)
-    const int f = blockIdx.z, batch = blockIdx.y, band = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     const uint8_t* img = src + static_cast<size_t>(f) * rows * cols * 3;
     const int groups = cols / 4, r0 = band * kFxSumRows, r1 = min(r0 + kFxSumRows, rows);
     const int gi = batch * 256 + tid, x = 4 * gi;
     const bool act = gi < groups;
-    for (int i = tid; i < kFxSumRows * 3 * 16; i += 256) (&sred[0][0][0])[i] = 0;
+    for (int i = tid; i < kFxSumRows * 3 * 64; i += 256) (&sred[0][0][0])[i] = 0;
     __syncthreads();
     const int flip = (pad & 1) ? -1 : 1;
     const bool plain = x > pad && x + 3 < cols - 1 - pad;                 // no pixel of the group is mirrored: weights +-1 by parity
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void fx_altsums(const uint8_t* __restrict__ sr
                         }
                 }
 #pragma unroll
-                for (int c = 0; c < 3; ++c) atomicAdd(&sred[r - r0][c][tid & 15], act ? s[c] : 0);
+                for (int c = 0; c < 3; ++c) atomicAdd(&sred[r - r0][c][tid & 63], act ? s[c] : 0);
                 // column sums: bytes 0, 2 of each dword in one packed pair, bytes 1, 3 in the other; |wy| = 1, 2 or 3 (uniform)
                 const uint32_t aw = static_cast<uint32_t>(wy < 0 ? -wy : wy);
 #pragma unroll
@@ -700,18 +700,36 @@ __global__ __launch_bounds__(256) void fx_altsums(const uint8_t* __restrict__ sr
     }
     __syncthreads();
     if (tid < (r1 - r0) * 3) {
-        const int* p16 = &sred[0][0][0] + 16 * tid;
+        const int* p64 = &sred[0][0][0] + 64 * tid;
         int v = 0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) v += p16[k];
+        for (int k = 0; k < 64; ++k) v += p64[(k + tid) & 63];              // (rotated: the 96 threads start on different banks)
         srow_part[((static_cast<size_t>(f) * nbatches + batch) * rows + r0) * 3 + tid] = v;
-        (&sred[0][0][0])[16 * tid] = v;                    // (slot 0 of its own 16: nobody else reads or writes it any more)
+        (&sred[0][0][0])[64 * tid] = v;                    // (slot 0 of its own 64: nobody else reads or writes it any more)
     }
     __syncthreads();
     if (tid < 3) {
         long long z = 0;
         for (int r = r0; r < r1; ++r) z += static_cast<long long>(mx_alt_weight(r, rows, pad)) * sred[r - r0][tid][0];
         zpart[((static_cast<size_t>(f) * nbands + band) * nbatches + batch) * 3 + tid] = z;
+    }
+}
+
+// One launch for everything that has to happen before the fused kernel: the quirk's sums (n_alt = bands x batches x frames workgroups,
+// none with nyquist_quirk = 0) and the edge strips (strip_blocks x nstrips x frames workgroups, last in the grid: they fill the tail)
+__global__ __launch_bounds__(256) void fx_prepass(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
+                                                  uint8_t* __restrict__ strips, int rows, int cols, int pad, int pada, int nbands, int nbatches, int n_alt, int chunks,
+                                                  int nright, int strip_blocks)
+{
+    __shared__ int sred[kFxSumRows][3][64];
+    int b = blockIdx.x;
+    if (b < n_alt) {
+        const int band = b % nbands, batch = (b / nbands) % nbatches, f = b / (nbands * nbatches);
+        fx_altsums_body(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred);
+    } else {
+        b -= n_alt;
+        const int nstrips = 1 + nright, bx = b % strip_blocks, sidx = (b / strip_blocks) % nstrips, f = b / (strip_blocks * nstrips);
+        fx_edge_strips_body(src, strips, rows, cols, pada, chunks, nright, bx, sidx, f);
     }
 }
 

@@ -32,7 +32,7 @@ def mean_counters(sub):
     for f in newest(os.path.join(src, sub, "**", "*counter_collection.csv")):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            m = re.search(r"((?:fast|wr|mx)_(?:row|col)pass\d*_u8|mx_altsums_reduce|mx_altsums|mx_quirk_terms|fx_blur_u8|fx_altsums|fx_edge_strips|fx_quirk_reduce|fx_quirk_cols)", k)
+            m = re.search(r"((?:fast|wr|mx)_(?:row|col)pass\d*_u8|mx_altsums_reduce|mx_altsums|mx_quirk_terms|fx_blur_u8|fx_prepass|fx_altsums|fx_edge_strips|fx_quirk_reduce|fx_quirk_cols)", k)
             name = m.group(1) if m else None
             if name:
                 acc[name][row["Counter_Name"]].append(float(row["Counter_Value"]))
