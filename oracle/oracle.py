@@ -296,6 +296,8 @@ def ref():
         for nm in ("ref_reflect_101_u8c3", "ref_reflect_101_u8c1", "ref_reflect_101_f32c1"):
             getattr(R, nm).argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, _i32p]
         R.ref_hybrid_loop_count.argtypes = [C.c_int, _i32p]
+        if hasattr(R, "ref_sorted_optimized_convolution"):
+            R.ref_sorted_optimized_convolution.argtypes = [_f32p, _f32p, C.c_int, C.c_float]
         _ref = R
     return _ref
 
@@ -305,6 +307,13 @@ def ref_get_gaussian(sigma, width=0, fft_length=0):
     k = np.zeros(max(w, fft_length), np.float32)
     ref().ref_get_gaussian(k, float(sigma), int(width), int(fft_length))
     return k
+
+
+def ref_sorted_optimized_convolution(tile_dft, kernel_dft, scaler):
+    """the reference's own pffft_sorted_optimized_convolution (Source.cpp:414-427), compiled from where it lies"""
+    t = np.array(tile_dft, np.float32)
+    ref().ref_sorted_optimized_convolution(t, np.ascontiguousarray(kernel_dft, np.float32), t.size, float(scaler))
+    return t
 
 
 def ref_reflect_101(img, pt, pb, pl, pr):

@@ -1,4 +1,4 @@
-// ---- end of Source.cpp:58-102
+// ---- end of Source.cpp:58-102, 414-427
 // ref_shim_tail.cpp -- C entry points over the reference's own functions.
 extern "C" {
 
@@ -42,6 +42,15 @@ void ref_hybrid_loop_count(int end, int* hits)
 #pragma omp atomic
         hits[i] += 1;
     });
+}
+
+// pffft_sorted_optimized_convolution (Source.cpp:414-427) on an ordered spectrum the way pffft_() calls it (Source.cpp:532,554):
+// tile_dft and kernel_dft are AlignedVector<float> of the transform length, scaler = 1 / N
+void ref_sorted_optimized_convolution(float* tile_dft, const float* kernel_dft, int size, float scaler)
+{
+    AlignedVector<float> t(tile_dft, tile_dft + size), k(kernel_dft, kernel_dft + size);
+    pffft_sorted_optimized_convolution(t, k, scaler);
+    std::copy(t.begin(), t.end(), tile_dft);
 }
 
 }  // extern "C"

@@ -63,6 +63,15 @@ def ref_vectors():
         out["rf_in_%d" % i] = arr
         out["rf_pads_%d" % i] = np.array(pads, np.int32)
         out["rf_out_%d" % i] = O.ref_reflect_101(arr, *pads)
+    # pffft_sorted_optimized_convolution (Source.cpp:414-427) on random ordered spectra: slot 0 (DC) and slot 1 (the Nyquist bin of
+    # pffft's ordered layout) are both scaled with kernel_dft[0] -- the quirk -- and every other pair with its own real part
+    for i, nn in enumerate((32, 96, 576, 2304, 4000)):
+        tile = rng.standard_normal(nn).astype(np.float32) * 100
+        kern = rng.uniform(0.0, 1.0, nn).astype(np.float32)
+        out["soc_tile_%d" % i] = tile
+        out["soc_kernel_%d" % i] = kern
+        out["soc_out_%d" % i] = O.ref_sorted_optimized_convolution(tile, kern, 1.0 / nn)
+    out["soc_n"] = np.array(5)
     np.savez_compressed(os.path.join(HERE, "ref_host_functions.npz"), **out)
     print("ref_host_functions.npz: %d gaussian_window cases, %d sizes, %d kernels, %d reflect cases" % (len(sig), len(n), len(cases), len(rcases)))
 

@@ -83,6 +83,21 @@ def test_reflect_101_matches_reference_vectors():
         assert np.array_equal(got, REFV["rf_out_%d" % i]), i
 
 
+def test_pointwise_rule_matches_the_reference_vectors():
+    """pffft_sorted_optimized_convolution (Source.cpp:414-427) is the one place where the reference's TEXT, not mathematics,
+    defines the result (slot 1 of the ordered layout, the Nyquist bin, is scaled with the DC gain kernel_dft[0]): the oracle's
+    restatement against outputs of the reference's own function (compiled from where it lies, oracle/Makefile), bit for bit"""
+    V = np.load(os.path.join(G, "ref_host_functions.npz"))
+    for i in range(int(V["soc_n"])):
+        tile, kern, want = V["soc_tile_%d" % i], V["soc_kernel_%d" % i], V["soc_out_%d" % i]
+        n = tile.size
+        got = O.sorted_optimized_convolution(tile, kern, 1.0 / n)
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        m0 = np.float32(kern[0] * np.float32(1.0 / n))
+        assert want[1] == np.float32(tile[1] * m0) and want[0] == np.float32(tile[0] * m0)       # the quirk: slot 1 gets slot 0's multiplier
+        assert want[3] == np.float32(tile[3] * np.float32(kern[2] * np.float32(1.0 / n)))        # imaginary parts get the real part's
+
+
 # ---- live against oracle/_ref (present in the build container and, prebuilt, on the GPU box)
 needs_ref = pytest.mark.skipif(not O.ref_available(), reason="oracle/_ref/libref_utils.so not built")
 
@@ -98,6 +113,17 @@ def test_live_reference_sizing_and_kernel():
         assert O.is_valid_size(int(n)) == O.ref().ref_is_valid_size(int(n))
     for s, w, f in [(rng.uniform(0.3, 60), 0, 0) for _ in range(20)] + [(20.0, 131, 2304), (2.2, 13, 64), (50.0, 331, 2560)]:
         assert np.array_equal(O.get_gaussian(s, w, f), O.ref_get_gaussian(s, w, f))
+
+
+@needs_ref
+def test_live_reference_pointwise_rule():
+    rng = np.random.default_rng(5)
+    for n in (32, 160, 1280, 4320):
+        tile = (rng.standard_normal(n) * 50).astype(np.float32)
+        kern = rng.uniform(-1, 1, n).astype(np.float32)
+        a = O.sorted_optimized_convolution(tile, kern, 1.0 / n)
+        b = O.ref_sorted_optimized_convolution(tile, kern, 1.0 / n)
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
 
 
 @needs_ref
