@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <list>
 #include <map>
 #include <memory>
 #include <string>
@@ -622,8 +623,7 @@ struct HostPipe {
 struct MxTables {
     void* frags_row = nullptr;   // [2][nkb][64][8] binary16 (host_math.hpp: mx_fragments)
     void* frags_col = nullptr;
-    float* taps_row = nullptr;   // 2 pad + 1 floats, centre at pad
-    float* taps_col = nullptr;
+    float* taps_row = nullptr;   // 2 pad + 1 floats, centre at pad (the same taps serve both axes)
     float dr = 0.f, dc = 0.f;    // m[0] - m[N/2] of the reference's row / column transform length (the quirk's gain)
 };
 
@@ -641,6 +641,8 @@ struct blur_ctx {
     float2* d_w256 = nullptr;
     std::map<int, float2*> wr_tw0;
     std::map<std::tuple<int, int, int, int, uint64_t>, float*> wr_spectra;   // (n, n_ref, ksize | -1, quirk, sigma bits | hash)
+    struct LinesTable { uint64_t hash; std::vector<float> host; float* dev; };
+    std::list<LinesTable> lines_tables;                                     // blur_convolve_lines_c32_dev: caller tables, LRU, bounded
     // matrix-core engine (mx_kernels.hpp): Toeplitz fragments + taps per kernel, integer sums and float terms of the quirk
     std::map<std::tuple<int, int, int, int, int, uint64_t>, MxTables> mx_tables;   // (ksize | -1, pad, nkb, n_row, n_col, sigma bits | hash)
     uint8_t* fx_strips = nullptr;   // fused kernel: the edge chunks' windows with the mirrored pixels in place
@@ -655,7 +657,7 @@ struct blur_ctx {
     size_t work2_bytes = 0;
     uint8_t* box_tmp = nullptr;
     size_t box_bytes = 0;
-    int last_family = -1;         // kernels the last u8c3 blur used: 0 run-time plans, 1 specialised rows-first, 2 wave-resident, 3 whole-image 2D, 4 matrix-core
+    int last_family = -1;         // kernels the last u8c3 blur used: 0 run-time plans, 1 specialised rows-first, 2 wave-resident, 3 whole-image 2D, 4 matrix-core (two kernels), 6 fused matrix-core
     void* host_stage = nullptr;   // device staging of the host-pointer entry points (kept between calls: no allocation per frame)
     size_t host_stage_bytes = 0;
     bool timing = false;
@@ -973,43 +975,56 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
     const int nn[2] = { sz.n_row, sz.n_col };
     uint64_t tag;
     int kkey;
-    for (int ax = 0; ax < 2; ++ax) {
-        const int n = nn[ax];
-        if (ck) {
-            karr[ax].assign(n, 0.f);
-            if (ck->box_klen > 0) box_kernel_1d(karr[ax].data(), ck->box_klen, n);
-            else {
-                if (ck->ksize > n) return refuse(BLUR_ERR_INVALID, "kernel longer than the padded line");
-                const int c = ck->ksize / 2;
-                for (int t = 0; t < ck->ksize; ++t) karr[ax][(t - c + n) % n] += ck->taps[t];
+    auto build_arrays = [&]() -> int {
+        for (int ax = 0; ax < 2; ++ax) {
+            const int n = nn[ax];
+            if (ck) {
+                karr[ax].assign(n, 0.f);
+                if (ck->box_klen > 0) box_kernel_1d(karr[ax].data(), ck->box_klen, n);
+                else {
+                    if (ck->ksize > n) return refuse(BLUR_ERR_INVALID, "kernel longer than the padded line");
+                    const int c = ck->ksize / 2;
+                    for (int t = 0; t < ck->ksize; ++t) karr[ax][(t - c + n) % n] += ck->taps[t];
+                }
+            } else {
+                karr[ax].assign(std::max(n, sz.kSize), 0.f);
+                get_gaussian(karr[ax].data(), sigma, sz.kSize, n);    // Source.cpp:75-102
             }
-        } else {
-            karr[ax].assign(std::max(n, sz.kSize), 0.f);
-            get_gaussian(karr[ax].data(), sigma, sz.kSize, n);    // Source.cpp:75-102
         }
-    }
-    if (ck) { kkey = -1; tag = fnv1a(karr[0].data(), nn[0] * sizeof(float)) ^ (fnv1a(karr[1].data(), nn[1] * sizeof(float)) * 3); }
-    else { kkey = sz.kSize; std::memcpy(&tag, &sigma, sizeof tag); }
+        return BLUR_OK;
+    };
+    // the Gaussian's key needs no kernel array: look it up before building one
+    if (ck) {
+        if (int rc = build_arrays()) return rc;
+        kkey = -1;
+        tag = fnv1a(karr[0].data(), nn[0] * sizeof(float)) ^ (fnv1a(karr[1].data(), nn[1] * sizeof(float)) * 3);
+    } else { kkey = sz.kSize; std::memcpy(&tag, &sigma, sizeof tag); }
     // (pad and nkb are part of the key: the same taps with another pad, or the two-kernel and the fused engine with different
     // window sizes for one pad, have different fragment tables)
     const auto key = std::make_tuple(kkey, pad, nkb, nn[0], nn[1], tag);
     auto it = ctx->mx_tables.find(key);
     if (it != ctx->mx_tables.end()) { *out = &it->second; return BLUR_OK; }
+    if (!ck) { if (int rc = build_arrays()) return rc; }
     MxTables t;
+    auto release = [&]() {                                        // a failure on the second axis must not leak the first one's tables
+        if (t.frags_row) (void)hipFree(t.frags_row);
+        if (t.frags_col) (void)hipFree(t.frags_col);
+        if (t.taps_row) (void)hipFree(t.taps_row);
+    };
     for (int ax = 0; ax < 2; ++ax) {
         const int n = nn[ax];
         std::vector<float> taps(2 * pad + 1);
         for (int k = -pad; k <= pad; ++k) taps[k + pad] = karr[ax][(k + n) % n];
         // anything of the kernel array outside +-pad would be lost here: the Toeplitz band is 2 pad + 1 wide
         for (int i = pad + 1; i < n - pad; ++i)
-            if (karr[ax][i] != 0.f) return refuse(BLUR_ERR_UNSUPPORTED, "matrix-core engine: kernel wider than 2 pad + 1");
-        // the 24-bit intermediate of the kernels (mx_kernels.hpp) covers [0, 256): non-negative taps with sum <= 1 keep the
+            if (karr[ax][i] != 0.f) { release(); return refuse(BLUR_ERR_UNSUPPORTED, "matrix-core engine: kernel wider than 2 pad + 1"); }
+        // the 24-bit intermediate of the two-kernel engine (mx_kernels.hpp) covers [0, 256): non-negative taps with sum <= 1 keep the
         // row pass inside 0..255.13 (the quirk's terms are added in f32 after it is decoded: no bound on them)
         {
             double sum = 0;
             bool neg = false;
             for (float t : taps) { sum += t; neg = neg || t < 0.f; }
-            if (neg || sum > 1.0005) return refuse(BLUR_ERR_UNSUPPORTED, "matrix-core engine: taps must be non-negative with sum <= 1");
+            if (neg || sum > 1.0005) { release(); return refuse(BLUR_ERR_UNSUPPORTED, "matrix-core engine: taps must be non-negative with sum <= 1"); }
         }
         std::vector<uint16_t> fr(static_cast<size_t>(2) * nkb * 512);
         mx_fragments(taps.data(), pad, nkb, fr.data());
@@ -1019,13 +1034,20 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
         const float scaler = 1.f / n;
         const float m0 = static_cast<float>(k0) * scaler, mh = static_cast<float>(kalt) * scaler;
         void* dfr = nullptr;
-        float* dt = nullptr;
-        HIP_TRY(ctx, hipMalloc(&dfr, fr.size() * sizeof(uint16_t)));
-        HIP_TRY(ctx, hipMemcpy(dfr, fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&dt), taps.size() * sizeof(float)));
-        HIP_TRY(ctx, hipMemcpy(dt, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
-        (ax ? t.frags_col : t.frags_row) = dfr;
-        (ax ? t.taps_col : t.taps_row) = dt;
+        hipError_t e = hipMalloc(&dfr, fr.size() * sizeof(uint16_t));
+        if (e == hipSuccess) {
+            (ax ? t.frags_col : t.frags_row) = dfr;
+            e = hipMemcpy(dfr, fr.data(), fr.size() * sizeof(uint16_t), hipMemcpyHostToDevice);
+        }
+        if (e == hipSuccess && ax == 0) {                        // the taps themselves: the fused engine's quirk terms convolve with them
+            e = hipMalloc(reinterpret_cast<void**>(&t.taps_row), taps.size() * sizeof(float));
+            if (e == hipSuccess) e = hipMemcpy(t.taps_row, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice);
+        }
+        if (e != hipSuccess) {
+            release();
+            ctx->err = std::string("matrix-core tables: ") + hipGetErrorString(e);
+            return BLUR_ERR_HIP;
+        }
         (ax ? t.dc : t.dr) = m0 - mh;
     }
     *out = &(ctx->mx_tables[key] = t);
@@ -1392,8 +1414,9 @@ int blur_ctx_destroy(blur_ctx* ctx)
     for (auto& kv : ctx->wr_spectra) (void)hipFree(kv.second);
     for (auto& kv : ctx->mx_tables) {
         (void)hipFree(kv.second.frags_row); (void)hipFree(kv.second.frags_col);
-        (void)hipFree(kv.second.taps_row); (void)hipFree(kv.second.taps_col);
+        (void)hipFree(kv.second.taps_row);
     }
+    for (auto& lt : ctx->lines_tables) (void)hipFree(lt.dev);
     if (ctx->fx_strips) (void)hipFree(ctx->fx_strips);
     if (ctx->mx_sums) (void)hipFree(ctx->mx_sums);
     if (ctx->mx_terms) (void)hipFree(ctx->mx_terms);
@@ -2102,6 +2125,7 @@ int blur_multi_create(blur_multi** out, const int* devices, int ndevices)
         if (rc == BLUR_OK) rc = blur_ctx_set_stream(c, st);
         if (rc != BLUR_OK) {
             if (c) blur_ctx_destroy(c);
+            if (st) (void)hipStreamDestroy(st);
             for (size_t i = 0; i < m->ctxs.size(); ++i) { blur_ctx_destroy(m->ctxs[i]); (void)hipStreamDestroy(m->streams[i]); }
             return rc;
         }
@@ -2209,14 +2233,32 @@ int blur_convolve_lines_c32_dev(blur_ctx* ctx, const float* d_in, float* d_out, 
     if (!e) return fail(ctx, BLUR_ERR_UNSUPPORTED, "no wave-resident kernel for this length (blur_wr_length)");
     float2* tw0 = nullptr;
     if (int rc = wr_get_tables(ctx, e, &tw0)) return rc;
-    const auto key = std::make_tuple(n, 0, -2, 0, fnv1a(multipliers, sizeof(float) * n));
+    // the caller's multiplier tables, cached by content (hash AND a full comparison: a colliding table would give a wrong image
+    // silently); at most kLinesCacheMax tables are kept, the least recently used one goes first
+    constexpr size_t kLinesCacheMax = 16;
     float* d_m = nullptr;
-    auto it = ctx->wr_spectra.find(key);
-    if (it != ctx->wr_spectra.end()) d_m = it->second;
-    else {
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_m), sizeof(float) * n));
-        HIP_TRY(ctx, hipMemcpy(d_m, multipliers, sizeof(float) * n, hipMemcpyHostToDevice));
-        ctx->wr_spectra[key] = d_m;
+    const uint64_t h = fnv1a(multipliers, sizeof(float) * n);
+    for (auto it = ctx->lines_tables.begin(); it != ctx->lines_tables.end(); ++it) {
+        if (it->hash == h && static_cast<int>(it->host.size()) == n && std::memcmp(it->host.data(), multipliers, sizeof(float) * n) == 0) {
+            d_m = it->dev;
+            ctx->lines_tables.splice(ctx->lines_tables.begin(), ctx->lines_tables, it);      // most recently used first
+            break;
+        }
+    }
+    if (!d_m) {
+        if (ctx->lines_tables.size() >= kLinesCacheMax) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));                                   // a launch may still read the table
+            (void)hipFree(ctx->lines_tables.back().dev);
+            ctx->lines_tables.pop_back();
+        }
+        // (the tail behind the table is only written by -DWR_STAMPS diagnostic builds, as in wr_get_spectrum)
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d_m), sizeof(float) * (n + kWrStampTailFloats)));
+        if (hipMemset(d_m, 0, sizeof(float) * (n + kWrStampTailFloats)) != hipSuccess ||
+            hipMemcpy(d_m, multipliers, sizeof(float) * n, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d_m);
+            return fail(ctx, BLUR_ERR_HIP, "blur_convolve_lines_c32_dev: table upload failed");
+        }
+        ctx->lines_tables.push_front({ h, std::vector<float>(multipliers, multipliers + n), d_m });
     }
     HIP_TRY(ctx, e->lines(ctx->stream, reinterpret_cast<const float2*>(d_in), reinterpret_cast<float2*>(d_out), nlines, ctx->num_cus, ctx->d_w256, tw0, d_m));
     return BLUR_OK;
@@ -2242,7 +2284,8 @@ int blur_wr_length(int need, int column_role)
 }
 
 // which kernels the last 8-bit 3-channel blur of this context ran: 0 run-time-planned, 1 specialised rows-first (both passes),
-// 2 wave-resident; -1 none yet (bench.py --preset reference-sweep reports it per size)
+// 2 wave-resident, 3 whole-image 2D transform, 4 two-kernel matrix-core engine, 6 fused matrix-core kernel; -1 none yet
+// (bench.py --preset reference-sweep reports it per size)
 int blur_debug_last_family(const blur_ctx* ctx) { return ctx ? ctx->last_family : -1; }
 
 // redzone tests: number of bytes of the workspace's two guard bands that were overwritten (0 = intact; -1 = no workspace yet)

@@ -247,7 +247,21 @@ template <class Mat, class = decltype(std::declval<Mat&>().size[0])> void pocket
 struct Image {
     std::vector<uint8_t> pixels;
     int size[2] = { 0, 0 };
-    uint8_t* data = nullptr;
+    uint8_t* data = nullptr;                            // = pixels.data(), like cv::Mat::data; kept right by the copy / move members
+    Image() = default;
+    Image(const Image& o) : pixels(o.pixels), data(pixels.empty() ? nullptr : pixels.data()) { size[0] = o.size[0]; size[1] = o.size[1]; }
+    Image(Image&& o) noexcept : pixels(std::move(o.pixels)), data(pixels.empty() ? nullptr : pixels.data())
+    {
+        size[0] = o.size[0]; size[1] = o.size[1];
+        o.data = nullptr; o.size[0] = o.size[1] = 0;
+    }
+    Image& operator=(Image o)
+    {
+        pixels.swap(o.pixels);
+        size[0] = o.size[0]; size[1] = o.size[1];
+        data = pixels.empty() ? nullptr : pixels.data();
+        return *this;
+    }
     int channels() const { return 3; }
     bool empty() const { return pixels.empty(); }
 };
@@ -265,11 +279,16 @@ inline Image imread(const std::string& path)
         }
         if (c < '0' || c > '9') return false;
         v = 0;
-        while (c >= '0' && c <= '9') { v = v * 10 + (c - '0'); c = std::fgetc(f); }
+        while (c >= '0' && c <= '9') {
+            if (v > 100000000) return false;            // a hostile header: no image side has nine digits
+            v = v * 10 + (c - '0');
+            c = std::fgetc(f);
+        }
         return true;                                    // the one whitespace byte after the number is consumed
     };
     int w = 0, h = 0, maxv = 0;
-    const bool ok = std::fgetc(f) == 'P' && std::fgetc(f) == '6' && token(w) && token(h) && token(maxv) && w > 0 && h > 0 && maxv == 255;
+    const bool ok = std::fgetc(f) == 'P' && std::fgetc(f) == '6' && token(w) && token(h) && token(maxv) && w > 0 && h > 0 && maxv == 255 &&
+                    static_cast<long long>(w) * h <= (1ll << 30);
     if (ok) {
         im.pixels.resize(static_cast<size_t>(w) * h * 3);
         if (std::fread(im.pixels.data(), 1, im.pixels.size(), f) == im.pixels.size()) {
