@@ -349,10 +349,11 @@ class BlurContext:
         self._check(self._lib.blur_gaussian_f32c1_dev(self._h, t.data_ptr(), dst.data_ptr(), t.shape[0], t.shape[1], float(sigma), C.byref(o)))
         return dst
 
-    def rowpass(self, image, sigma, nyquist_quirk=True, force_generic=False):
-        """row pass only: uint8 [rows, cols, 3] CUDA tensor -> float32 [3, rows, cols] (Source.cpp:520-537)"""
+    def rowpass(self, image, sigma, nyquist_quirk=True, force_generic=False, engine=None):
+        """row pass only: uint8 [rows, cols, 3] CUDA tensor -> float32 [3, rows, cols] (Source.cpp:520-537); engine="fused": the planes the
+        fused matrix-core kernel hands from its row pass to its column pass (a test build of the kernel writes them out)"""
         import torch
-        o = self._opts(nyquist_quirk, 0, force_generic)
+        o = self._opts(nyquist_quirk, 0, force_generic, engine=engine)
         rows, cols = image.shape[0], image.shape[1]
         planes = torch.empty((3, rows, cols), dtype=torch.float32, device=image.device)
         self.use_torch_stream()

@@ -637,6 +637,7 @@ struct blur_ctx {
     std::map<std::tuple<int, int, int, uint64_t>, float*> spectra;
     std::map<int, float*> last_spectrum;   // n -> most recent table (diagnostic stamp read-back)
     int num_cus = 256;           // hipDeviceProp_t::multiProcessorCount
+    int num_xcds = 8;            // hipDeviceAttributeNumberOfXccs
     // wave-resident engine (wr_kernels.hpp): shared 256-point twiddles, pass-0 twiddles per R0, multiplier tables
     float2* d_w256 = nullptr;
     std::map<int, float2*> wr_tw0;
@@ -1395,6 +1396,8 @@ int blur_ctx_create(blur_ctx** out, int device)
     c->device = device;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) c->num_cus = prop.multiProcessorCount;
+    int xccs = 0;   // the XCD-banded task maps of the matrix-core kernels (fx_kernels.hpp, mx_kernels.hpp) take the count from the device
+    if (hipDeviceGetAttribute(&xccs, hipDeviceAttributeNumberOfXccs, device) == hipSuccess && xccs > 0) c->num_xcds = xccs;
     *out = c;
     return BLUR_OK;
 }
@@ -1489,7 +1492,7 @@ int blur_ctx_timing(blur_ctx* ctx, double out_ms[2], int out_launches[2], int ou
 static int run_mx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes, int rows, int cols, int chunk, const Prepared& p)
 {
     const size_t px = static_cast<size_t>(rows) * cols;
-    MxGeom g{ rows, cols, p.sz.pad, p.mx_vpitch, 0, 0, mx_vrows(rows, p.mx->nkb) };
+    MxGeom g{ rows, cols, p.sz.pad, p.mx_vpitch, 0, 0, mx_vrows(rows, p.mx->nkb), ctx->num_xcds };
     const int chunks = (cols + kMxRowChunk - 1) / kMxRowChunk, rblocks = g.vrows / 32, zblocks = (g.vrows + 255) / 256;
     // the quirk's scratch per frame: spart int [chunks][rows][3]; then floats: vpart [rblocks][vpitch], qrow [3][vrows], qcol [vpitch];
     // then doubles: zpart [zblocks][3]
@@ -1541,7 +1544,7 @@ static int run_mx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
 }
 
 // both passes in one kernel on the matrix cores (fx_kernels.hpp): no intermediate in memory
-static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes, int rows, int cols, const Prepared& p)
+static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes, int rows, int cols, const Prepared& p, float* vdump = nullptr)
 {
     const size_t px = static_cast<size_t>(rows) * cols;
     // in place (the reference's own calling convention, Source.cpp:429,567): a strip reads its neighbours' columns and the rows
@@ -1554,7 +1557,7 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         d_src = reinterpret_cast<const uint8_t*>(ctx->work);
     }
     const int nkb = p.fx->nkb, pada = 8 * (nkb - 2), nt = (nkb - 1) / 2;
-    FxGeom g{ rows, cols, p.sz.pad, nframes, 0, (rows + 31) / 32, fx_right_strips(cols, pada) };
+    FxGeom g{ rows, cols, p.sz.pad, nframes, 0, (rows + 31) / 32, fx_right_strips(cols, pada), ctx->num_xcds };
     g.aligned = ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 3) == 0) ? 1 : 0;
     if (!g.aligned) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: frame pointers must be 4-byte aligned");
     const int qrows = 32 * (g.ntiles + nt), qpitch = (3 * cols + 31) & ~31;
@@ -1624,7 +1627,7 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         qcol = reinterpret_cast<float*>(stamps);
     }
     { TimedLaunch t(ctx, 0, nframes);
-      HIP_TRY(ctx, p.fx->blur_u8(ctx->stream, d_src, d_dst, p.mxt->frags_row, g, ctx->num_cus, qrow, qcol, qpitch, ctx->fx_strips)); }
+      HIP_TRY(ctx, p.fx->blur_u8(ctx->stream, d_src, d_dst, p.mxt->frags_row, g, ctx->num_cus, qrow, qcol, qpitch, ctx->fx_strips, vdump)); }
     if (stamps) {
         unsigned long long h[8];
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1751,6 +1754,14 @@ int blur_rowpass_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, float* d_planes, 
     if (!ctx) return BLUR_ERR_INVALID;
     if (!d_src || !d_planes) return fail(ctx, BLUR_ERR_INVALID, "null pointer");
     Prepared p;
+    if (opts && opts->engine == BLUR_ENGINE_FUSED) {
+        // the fused kernel's row-pass planes (tests): the whole blur runs, its bytes go to the workspace and are dropped
+        const bool aligned = (reinterpret_cast<uintptr_t>(d_src) & 3) == 0;
+        if (int rc = prepare(ctx, rows, cols, sigma, opts, p, true, nullptr, true, aligned)) return rc;
+        const size_t bytes = static_cast<size_t>(rows) * cols * 3;
+        if (int rc = ensure_work(ctx, 2 * bytes + 64)) return rc;
+        return run_fx_u8c3(ctx, d_src, reinterpret_cast<uint8_t*>(ctx->work) + ((bytes + 63) & ~static_cast<size_t>(63)), 1, rows, cols, p, d_planes);
+    }
     if (int rc = prepare(ctx, rows, cols, sigma, opts, p, true, nullptr, false)) return rc;   // the rows-first kernels: row-major planes
     return run_rowpass_u8c3(ctx, d_src, d_planes, rows, cols, 1, p, 0);   // always row-major for the caller
 }

@@ -48,6 +48,7 @@ struct FxGeom {
     int aligned;      // 1: cols % 4 == 0 and frame pointers 4-byte aligned: 12-byte pixel groups are three aligned dwords
     int ntiles;       // output tiles of 32 rows per frame
     int nright;       // chunks at the right edge that read their window from a strip (the chunk at the left edge always does)
+    int nxcd;         // XCDs of the device (hipDeviceAttributeNumberOfXccs): workgroup b runs on XCD b % nxcd
 };
 
 constexpr int kFxChunk = 128;     // pixel columns per workgroup
@@ -104,10 +105,12 @@ __device__ __forceinline__ uint32_t fx_quad_transpose(uint32_t p, uint32_t sel1,
 // (15 of the column pass + the row pass's): C(n) begins with the tile that FINISHES (its last window block) and ends with the
 // tile that STARTS, which takes over the finished tile's registers after E(n) has read them; the row accumulator is read out
 // by S(n+1) early in B(n), before R(n+2) writes it again.
-template <int NKB, bool QUIRK>
+// DUMPV (tests only, blur_rowpass_u8c3_dev with BLUR_ENGINE_FUSED): the row pass's float planes V' (quirk term included), as the
+// hand-off reads them, also go to vdump[frame][channel][row][col] -- what the reference holds in `resf` after Source.cpp:520-537.
+template <int NKB, bool QUIRK, bool DUMPV = false>
 __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, FxGeom g,
                                                      int chunks, int tps, int nseg, int ntasks, const float* __restrict__ qrow, const float* __restrict__ qcol,
-                                                     int qpitch, const uint8_t* __restrict__ strips)
+                                                     int qpitch, const uint8_t* __restrict__ strips, float* __restrict__ vdump)
 {
     using C = FxCfg<NKB>;
     constexpr int PADA = C::PADA, PW = C::PW, NT = C::NT, PER = C::PER;
@@ -117,8 +120,8 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 
     // tasks are numbered chunk-fastest; workgroups b and b + 8 share an XCD: every XCD gets a contiguous band of tasks, so the
     // strips left and right of a strip -- which read 2 PADA of its window columns -- run on the same L2 at about the same time
-    const int xcd = blockIdx.x & 7, per_xcd = (ntasks + 7) / 8, task = xcd * per_xcd + (blockIdx.x >> 3);
-    if ((blockIdx.x >> 3) >= per_xcd || task >= ntasks) return;
+    const int nx = g.nxcd, xcd = blockIdx.x % nx, in_xcd = blockIdx.x / nx, per_xcd = (ntasks + nx - 1) / nx, task = xcd * per_xcd + in_xcd;
+    if (in_xcd >= per_xcd || task >= ntasks) return;
     const int xc = task % chunks, seg = (task / chunks) % nseg, f = task / (chunks * nseg);
     const int x0 = xc * kFxChunk;
     const int tile0 = seg * tps, tile1 = min(tile0 + tps, g.ntiles);
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     // {read + scale -> sv, convert two row pairs, convert the other two, exchange}).  Phase B(n) runs the two read pieces of product n + 1 (the row accumulator is
     // free again before R(n + 2) starts), phase A(n + 1) the other four: B is the phase whose vector work fills its matrix time
     float sv[16];
-    auto split_piece = [&](int buf, int c, int piece) __attribute__((always_inline)) {
+    auto split_piece = [&](int buf, int c, int piece, int sprod = 0) __attribute__((always_inline)) {
         const int hf = piece / 4, sub = piece % 4;       // sub: 0 read + scale, 1 / 2 convert row pairs 0, 1 / 2, 3, 3 exchange
         uint32_t (&hp)[8] = hl[0];
         uint32_t (&lp)[8] = hl[1];
@@ -303,6 +306,14 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
             } else {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) sv[8 * hf + k] = arow[8 * hf + k] * kFxRowUnscale;
+            }
+            if (DUMPV) {
+                const int x = x0 + 32 * wave + m;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int reg = 8 * hf + k, r = 32 * sprod + (reg & 3) + 8 * (reg >> 2) + 4 * h - PADA;
+                    if (r >= 0 && r < g.rows && x < g.cols) vdump[((static_cast<size_t>(f) * 3 + c) * g.rows + r) * g.cols + x] = sv[8 * hf + k];
+                }
             }
         } else if (sub == 1 || sub == 2) {
 #pragma unroll
@@ -426,8 +437,8 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     issue_chunk(s0 + 2, 0);
     __syncthreads();
     rowpass(0, 0, [](int) {});
-    split_piece(0, 0, 0);
-    split_piece(0, 0, 4);
+    split_piece(0, 0, 0, s0);
+    split_piece(0, 0, 4, s0);
 
 #ifdef FX_STAMPS
     // timing-only build: cycles (s_memtime) per phase kind, summed over the steps, by wave 0 of workgroup 0 -> the buffer passed as qcol
@@ -492,11 +503,11 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
                         if (NKB >= 11) {
                             // S (read pieces) after triples 1, 2; E: row groups after triples 3 .. 6 (the tile that starts takes the
                             // finished tile's registers in triple NKB - 2)
-                            if (it == 1) split_piece(nbuf, nc, 0);
-                            if (it == 2) split_piece(nbuf, nc, 4);
+                            if (it == 1) split_piece(nbuf, nc, 0, c == 2 ? s + 1 : s);
+                            if (it == 2) split_piece(nbuf, nc, 4, c == 2 ? s + 1 : s);
                             if (it >= 3 && it <= 6) emit_piece(c, it - 3);
                         } else {
-                            if (it == (NKB >= 5 ? 1 : 0)) { split_piece(nbuf, nc, 0); split_piece(nbuf, nc, 4); }
+                            if (it == (NKB >= 5 ? 1 : 0)) { split_piece(nbuf, nc, 0, c == 2 ? s + 1 : s); split_piece(nbuf, nc, 4, c == 2 ? s + 1 : s); }
                             if (it == (NKB >= 5 ? NKB - 3 : 0)) {
 #pragma unroll
                                 for (int gq = 0; gq < 4; ++gq) emit_piece(c, gq);
@@ -825,11 +836,11 @@ __global__ __launch_bounds__(256) void fx_quirk_cols(const int* __restrict__ cco
 struct FxEntry {
     int nkb;
     hipError_t (*blur_u8)(hipStream_t, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const float* qrow, const float* qcol, int qpitch,
-                          const uint8_t* strips);
+                          const uint8_t* strips, float* vdump);
 };
 
 template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const float* qrow,
-                                           const float* qcol, int qpitch, const uint8_t* strips)
+                                           const float* qcol, int qpitch, const uint8_t* strips, float* vdump)
 {
     using C = FxCfg<NKB>;
     const int chunks = (g.cols + kFxChunk - 1) / kFxChunk;
@@ -848,22 +859,25 @@ template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, u
         }
     }
     const long long ntasks = nstripes * nseg;
-    const int per_xcd = static_cast<int>((ntasks + 7) / 8);
-    const dim3 grid(static_cast<unsigned>(8 * per_xcd));
+    if (g.nxcd < 1) g.nxcd = 1;
+    const int per_xcd = static_cast<int>((ntasks + g.nxcd - 1) / g.nxcd);
+    const dim3 grid(static_cast<unsigned>(g.nxcd * per_xcd));
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(fx_blur_u8<NKB, true>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-        if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(fx_blur_u8<NKB, false>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
-        if (e != hipSuccess) return e;
+        const void* kernels[4] = { reinterpret_cast<const void*>(fx_blur_u8<NKB, true, false>), reinterpret_cast<const void*>(fx_blur_u8<NKB, false, false>),
+                                   reinterpret_cast<const void*>(fx_blur_u8<NKB, true, true>), reinterpret_cast<const void*>(fx_blur_u8<NKB, false, true>) };
+        for (const void* k : kernels) {
+            const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
+            if (e != hipSuccess) return e;
+        }
         attr_done = true;
     }
-    if (qrow)
-        hipLaunchKernelGGL((fx_blur_u8<NKB, true>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg,
-                           static_cast<int>(ntasks), qrow, qcol, qpitch, strips);
-    else
-        hipLaunchKernelGGL((fx_blur_u8<NKB, false>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg,
-                           static_cast<int>(ntasks), qrow, qcol, qpitch, strips);
+#define FX_LAUNCH(Q_, D_)                                                                                                                                  \
+    hipLaunchKernelGGL((fx_blur_u8<NKB, Q_, D_>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg,     \
+                       static_cast<int>(ntasks), qrow, qcol, qpitch, strips, vdump)
+    if (vdump) { if (qrow) FX_LAUNCH(true, true); else FX_LAUNCH(false, true); }
+    else { if (qrow) FX_LAUNCH(true, false); else FX_LAUNCH(false, false); }
+#undef FX_LAUNCH
     return hipGetLastError();
 }
 

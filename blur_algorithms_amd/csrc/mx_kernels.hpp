@@ -87,6 +87,7 @@ struct MxGeom {
     int aligned;      // 1: 12-byte pixel groups of the source can be read as three aligned dwords
     int vrows;        // rows of V per frame: the image rows with their reflect-101 border ABOVE AND BELOW already in place
                       // (row re of V = image row refl(re - PADA)), so the column pass never reflects: 32 ntiles + 2 PADA
+    int nxcd;         // XCDs of the device (hipDeviceAttributeNumberOfXccs): workgroup b runs on XCD b % nxcd
 };
 __host__ __device__ constexpr int mx_vrows(int rows, int nkb) { return 32 * ((rows + 31) / 32) + 32 * ((16 * (nkb - 2) + 31) / 32); }
 
@@ -247,14 +248,14 @@ __global__ __launch_bounds__(256, (NKB <= 17 ? 2 : 1)) void mx_rowpass_u8(const 
         th[kb] = frags[kb * 64 + lane];
         tl[kb] = frags[(NKB + kb) * 64 + lane];
     }
-    // Workgroups b and b + 8 run on the same XCD and share its L2.  Give every XCD a contiguous band of units (units are
+    // Workgroups b and b + nxcd (8 on MI355X) run on the same XCD and share its L2.  Give every XCD a contiguous band of units (units are
     // numbered chunk-fastest), so that the chunks left and right of a unit -- which read 2 PADA of its 128 + 2 PADA window
     // columns -- are the same XCD's work at about the same time: without this the window overlap was fetched from memory
     // 2.5 times (PMC: 489 MB read for 199 MB of frames, profiles/r02mx_pmc_counters.json).
-    const int xcd = blockIdx.x & 7, per_xcd = (nunits + 7) / 8, lanes_x = (gridDim.x + 7 - xcd) / 8;     // workgroups of this XCD
+    const int nx = g.nxcd, xcd = blockIdx.x % nx, per_xcd = (nunits + nx - 1) / nx, lanes_x = (gridDim.x + nx - 1 - xcd) / nx;     // workgroups of this XCD
     const int ubeg = xcd * per_xcd, uend = min(nunits, ubeg + per_xcd);
     MxRowRaw<NKB> raw;
-    int u = ubeg + (blockIdx.x >> 3);
+    int u = ubeg + blockIdx.x / nx;
     const int ustep = lanes_x;
     if (u < uend) mx_row_issue<NKB>(raw, src, g, u, chunks, rblocks, tid);
     for (; u < uend; u += ustep) {

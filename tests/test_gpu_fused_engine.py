@@ -3,7 +3,7 @@ library's choice where it applies) against the float64 oracle under the same par
 import numpy as np
 import pytest
 
-from conftest import assert_u8_parity
+from conftest import FLOAT_TOL, assert_u8_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -41,6 +41,23 @@ def test_fused_engine_matches_the_oracle(ctx, rows, cols, sigma, quirk):
     auto = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, nyquist_quirk=quirk).cpu().numpy()
     assert _fam(ctx) == 6
     assert np.array_equal(auto, got)
+
+
+@pytest.mark.parametrize("rows,cols,sigma", [(270, 480, 20.0), (131, 152, 18.0), (97, 644, 19.0), (70, 68, 20.0), (66, 132, 20.0), (200, 332, 6.0), (150, 260, 2.0)])
+@pytest.mark.parametrize("quirk", [True, False])
+def test_fused_engine_row_pass_float_planes(ctx, rows, cols, sigma, quirk):
+    """the float planes the fused kernel hands from its row pass to its column pass (a test instantiation of the same kernel
+    writes them out through blur_rowpass_u8c3_dev) against the oracle's `resf` planes (Source.cpp:520-537), Nyquist term of the
+    row transform included, at the tolerance the FFT kernels' planes are held to"""
+    from oracle import oracle as O
+    torch = _torch()
+    img = _rand_img(rows, cols, 5 * rows + cols)
+    planes = ctx.rowpass(torch.from_numpy(img).cuda(), sigma, nyquist_quirk=quirk, engine="fused").cpu().numpy()
+    assert _fam(ctx) == 6
+    for c in range(3):
+        _, inter = O.pffft_plane_f64(img[:, :, c].astype(np.float32), sigma, quirk, want_inter=True)
+        err = np.abs(planes[c].astype(np.float64) - inter).max()
+        assert err <= FLOAT_TOL, "channel %d: max |err| %.3g" % (c, err)
 
 
 # one sigma per instantiated window size (NKB = 3, 5, 7, 9, 11: pad <= 8, 24, 40, 56, 72); sigma 2.0 is the truncated Gaussian
