@@ -1,0 +1,262 @@
+// fastboxblur (call site Source.cpp:587; semantics: oracle/boxblur_oracle.c) on v_mfma_i32_16x16x64_i8.
+//
+// One sweep of a box of 2 r + 1 taps is a banded matrix of ones applied along the sweep direction.  A wave walks along that
+// direction in steps of 16 positions and keeps, per 16 lines and per sweep, a WINDOW of 64 NB positions as the B operand of the
+// matrix instruction (lane = line, 16 bytes = 16 positions each of the 4 lane groups: exactly 64 per instruction); the band is the
+// A operand (constants), so ONE instruction (NB of them for boxes wider than 49) gives the 16 x 16 running sums of the step -- no
+// recurrence, nothing to set up when a segment starts.  The accumulator comes out with the line on the lane and four consecutive
+// positions in its four registers, which is, byte for byte, the layout of the next window dword of the SAME lane: the u8 result of
+// sweep p (one v_mul_hi_u32_u24 per byte, below) is the input of sweep p + 1 with no lane movement, and the P sweeps run as a
+// pipeline inside the wave: image bytes are read once and written once per direction (6 B/px for three channels instead of 6 P).
+//
+// Signed operands.  The instruction multiplies signed bytes, so windows hold x - 128 (x ^ 0x80) and the sums are put right by the
+// accumulator's start value.
+//
+// Rounding.  The oracle's (uint8)(int)(acc * (1.f / n) + 0.5f), n = 2 r + 1 odd, equals floor((acc + r) / n): acc / n + 1/2 is
+// never closer than 1 / (2 n) to an integer and the float error is below 5e-5.  The band's entries are s (64; 127 for n = 3) and
+// the accumulator starts at s r, so the instruction delivers s (acc + r) < 2^24, and the high half of its 24 x 24-bit product with
+// M = ceil(2^32 / (s n)) is that floor exactly (error term (acc + r + 256 n) s n / 2^32 < 1 / n for n < 400) -- written straight into
+// byte k of the packed dword by the SDWA form of the multiply.
+//
+// Borders.  The blur of a reflect-101 extension is the extension of the blur (the window is symmetric and the sums are integers),
+// so margins are never special: the vertical kernel reads mirrored rows, the horizontal one reads mirrored margins that a small
+// kernel lays out beside the image first; the sweeps' intermediate values at positions outside the image are then the mirrored
+// intermediate values, as the oracle's per-sweep reflect requires.
+#include "bx_box.hpp"
+
+namespace blur_amd {
+namespace {
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+
+constexpr uint32_t kRsrcWord3 = 0x00020000u;   // raw buffer, 32-bit data format (gfx9 family)
+constexpr uint32_t kDropped = 0xfffffff0u;     // an offset past every buffer: the store is dropped, the load returns 0
+
+template <int CTRL> __device__ __forceinline__ uint32_t bx_dpp(uint32_t x)
+{
+    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, 0xf, 0xf, true));
+}
+
+// 4 x 4 byte transpose inside a lane quad: lane j holds bytes M[j][0..3]; afterwards lane k holds M[0..3][k]
+__device__ __forceinline__ uint32_t bx_quad_transpose(uint32_t p, uint32_t sel1, uint32_t sel2)
+{
+    const uint32_t t = bx_dpp<0xb1>(p);                       // quad_perm [1,0,3,2]
+    const uint32_t q = __builtin_amdgcn_perm(t, p, sel1);
+    const uint32_t u = bx_dpp<0x4e>(q);                       // quad_perm [2,3,0,1]
+    return __builtin_amdgcn_perm(u, q, sel2);
+}
+
+// the four sums of a lane -> four bytes of one dword: floor(sum / (s n)) each (sum = s (acc + r), see the header); the low byte
+// of each quotient (the sweeps that feed another sweep deliver v + 128 < 384: the byte wraps to v ^ 0x80).  Plain C on purpose:
+// the compiler pads the matrix-result -> vector-read and vector-write -> matrix-operand hazards of its own instructions only
+// (an SDWA form of the multiply, written as inline assembly, packs in 4 instructions instead of 7 but its last byte reached the
+// next matrix instruction too late: +-1 on 2 % of the bytes for r >= 12).
+__device__ __forceinline__ uint32_t bx_mulhi24(int d, uint32_t mul)
+{
+    return static_cast<uint32_t>((static_cast<uint64_t>(static_cast<uint32_t>(d) & 0xffffffu) * (mul & 0xffffffu)) >> 32);
+}
+__device__ __forceinline__ uint32_t bx_pack(v4i d, uint32_t mul)
+{
+    const uint32_t lo = __builtin_amdgcn_perm(bx_mulhi24(d[1], mul), bx_mulhi24(d[0], mul), 0x0c0c0400u);
+    const uint32_t hi = __builtin_amdgcn_perm(bx_mulhi24(d[3], mul), bx_mulhi24(d[2], mul), 0x04000c0cu);
+    return lo | hi;
+}
+
+// The band.  The window of a sweep is a ring of W = 4 NB dwords per lane (newest at ring slot step % W); dword d of operand group
+// G is ring slot 4 G + d and holds, in lane group q, the positions 16 t + 4 q + i (i = byte) of window tile t = W - 1 - age,
+// age = (step - slot) mod W.  The step's 16 outputs are the window's positions DELTA .. DELTA + 15, DELTA = 32 NB - 8 (the
+// middle), output m on lane m of the A operand.  Fragment u = (step - 4 G) mod W serves group G: bx_band(u)[d] byte i is s where
+// |16 t + 4 q + i - DELTA - m| <= reach with age = (u - d) mod W.  `stride`: taps sit on every stride-th position (the channel
+// count for the horizontal sweeps over interleaved pixels, 1 for the vertical ones); reach = stride r.
+template <int NB> __device__ __forceinline__ v4i bx_band(int u, int m, int q, int r, int stride, int s)
+{
+    constexpr int W = 4 * NB, DELTA = 32 * NB - 8;
+    v4i a;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int age = (u - d + W) % W, t = W - 1 - age;
+        uint32_t word = 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int off = 16 * t + 4 * q + i - DELTA - m, ao = off < 0 ? -off : off;
+            if (ao <= stride * r && ao % stride == 0) word |= static_cast<uint32_t>(s) << (8 * i);
+        }
+        a[d] = static_cast<int>(word);
+    }
+    return a;
+}
+
+// ---- vertical ------------------------------------------------------------------------------------------------------------
+// A wave owns a strip of 16 NT byte columns and a segment of rows.  Lane (n = l & 15, q = l >> 4), quad qd = n >> 2, p = n & 3:
+// per step it loads NT dwords (as dwordx4) of row 16 step + 4 q + p, bytes 4 NT qd .. of the strip -- a wave's load covers 16 rows
+// x 16 NT contiguous bytes -- and a 4 x 4 byte transpose inside the quad turns dword t into "column 16 qd + 4 t + p of the strip,
+// rows 4 q .. 4 q + 3": the window dword of tile t (tile t = the strip's columns 16 qd' + 4 t + p', any assignment of columns to
+// tiles will do).  Stores take the same road back.  Sweep p's tile of step s covers rows R0 - p DELTA + 16 s ..: the walk starts
+// P DELTA rows above the segment and the first P (W - 1) steps only fill the pipeline.
+template <int NB, int P, int NT>
+__global__ __launch_bounds__(256) void bx_vert_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int h, int pitch, int r, int s_band, uint32_t mul,
+                                                      int seg_rows, int nstrips, int nwaves)
+{
+    constexpr int W = 4 * NB, DELTA = 32 * NB - 8, FILL = P * (W - 1);
+    static_assert(NT % 4 == 0, "dwordx4 loads");
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nwaves) return;
+    const int l = threadIdx.x & 63, n = l & 15, q = l >> 4, qd = n >> 2, p = n & 3;
+    const int strip = wid % nstrips, seg = wid / nstrips;
+    const int ys = seg * seg_rows, ye = min(h, ys + seg_rows);
+    const int S = FILL + (ye - ys + 15) / 16, R0 = ys - P * DELTA;
+    const uint32_t col0 = static_cast<uint32_t>(strip) * (16 * NT) + 4 * NT * qd;
+    const uint32_t sel1 = (l & 1) ? 0x03070105u : 0x06020400u, sel2 = (l & 2) ? 0x03020706u : 0x05040100u;
+    const uint32_t bytes = static_cast<uint32_t>(h) * static_cast<uint32_t>(pitch);
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(in), 0, bytes, kRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out, 0, bytes, kRsrcWord3);
+    const bool whole16 = (pitch & 15) == 0;
+
+    v4i band[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) band[u] = bx_band<NB>(u, n, q, r, 1, s_band);
+    // the instruction's operands are SIGNED bytes: windows hold x ^ 0x80 = x - 128, the accumulator starts at s (128 n + r) more,
+    // and the sweeps that feed another sweep add 128 to their result on the way out (another s 128 n: the byte wraps to v ^ 0x80)
+    const int nt = 2 * r + 1, bias_last = s_band * (128 * nt + r), bias_mid = s_band * (256 * nt + r);
+    const v4i cin_last = { bias_last, bias_last, bias_last, bias_last }, cin_mid = { bias_mid, bias_mid, bias_mid, bias_mid };
+
+    uint32_t win[P][NT][W];
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int d = 0; d < W; ++d) win[a][t][d] = 0;
+
+    u4 ld[2][NT / 4];
+    auto issue = [&](int s, u4 (&dst)[NT / 4]) __attribute__((always_inline)) {
+        int row = R0 + 16 * s + 4 * q + p;
+        row = row < 0 ? -row : row;
+        row = row >= h ? 2 * (h - 1) - row : row;
+        const uint32_t off = static_cast<uint32_t>(row) * static_cast<uint32_t>(pitch) + col0;
+#pragma unroll
+        for (int k = 0; k < NT / 4; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b128(rin, off + 16 * k, 0, 0);
+    };
+    issue(0, ld[0]);
+    if (S > 1) issue(1, ld[1]);
+
+    for (int s0 = 0; s0 < S; s0 += 2 * W) {
+#pragma unroll
+        for (int uu = 0; uu < 2 * W; ++uu) {
+            const int s = s0 + uu, slot = uu % W;
+            if (s >= S) break;
+            u4 (&cur)[NT / 4] = ld[uu & 1];
+            uint32_t res[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                win[0][t][slot] = bx_quad_transpose(cur[t / 4][t % 4], sel1, sel2) ^ 0x80808080u;
+#pragma unroll
+                for (int a = 0; a < P; ++a) {
+                    v4i d = a + 1 < P ? cin_mid : cin_last;
+#pragma unroll
+                    for (int G = 0; G < NB; ++G) {
+                        const v4i b = { static_cast<int>(win[a][t][4 * G]), static_cast<int>(win[a][t][4 * G + 1]), static_cast<int>(win[a][t][4 * G + 2]),
+                                        static_cast<int>(win[a][t][4 * G + 3]) };
+                        d = __builtin_amdgcn_mfma_i32_16x16x64_i8(band[(slot - 4 * G + W) % W], b, d, 0, 0, 0);
+                    }
+                    const uint32_t pk = bx_pack(d, mul);
+                    if (a + 1 < P) win[a + 1][t][slot] = pk; else res[t] = pk;
+                }
+            }
+            if (s + 2 < S) issue(s + 2, cur);
+            if (s >= FILL) {
+                const int row = ys + 16 * (s - FILL) + 4 * q + p;
+                const bool rok = row < ye;
+                const uint32_t off = static_cast<uint32_t>(row) * static_cast<uint32_t>(pitch) + col0;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) res[t] = bx_quad_transpose(res[t], sel1, sel2);
+                if (whole16) {
+#pragma unroll
+                    for (int k = 0; k < NT / 4; ++k) {
+                        const u4 w = { res[4 * k], res[4 * k + 1], res[4 * k + 2], res[4 * k + 3] };
+                        const bool ok = rok && col0 + 16 * k < static_cast<uint32_t>(pitch);
+                        __builtin_amdgcn_raw_buffer_store_b128(w, rout, ok ? off + 16 * k : kDropped, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const bool ok = rok && col0 + 4 * t < static_cast<uint32_t>(pitch);
+                        __builtin_amdgcn_raw_buffer_store_b32(res[t], rout, ok ? off + 4 * t : kDropped, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// band entry and multiplier for a box of n = 2 r + 1 taps (see the header); false: outside the exact range
+bool bx_constants(int r, int* s_band, uint32_t* mul)
+{
+    const long long n = 2ll * r + 1;
+    if (r < 1 || n >= 400) return false;
+    const int s = n >= 5 ? 64 : 127;
+    const unsigned long long m = ((1ull << 32) + static_cast<unsigned long long>(s * n) - 1) / static_cast<unsigned long long>(s * n);
+    if (m >= (1ull << 24)) return false;
+    *s_band = s;
+    *mul = static_cast<uint32_t>(m);
+    return true;
+}
+
+template <int NB, int P, int NT>
+hipError_t bx_launch_vert(hipStream_t st, const uint8_t* in, uint8_t* out, int h, int pitch, int r, int s_band, uint32_t mul, int num_cus)
+{
+    constexpr int DELTA = 32 * NB - 8, W = 4 * NB;
+    const int nstrips = (pitch + 16 * NT - 1) / (16 * NT);
+    // segments: as few as give every SIMD a wave or two (each pays P (W - 1) steps to fill its pipeline)
+    const int fill_rows = 16 * P * (W - 1);
+    int nseg = (8 * num_cus + nstrips - 1) / nstrips;
+    const int most = (h + 4 * fill_rows - 1) / (4 * fill_rows) > 0 ? h / (2 * fill_rows) : 1;
+    if (nseg > most) nseg = most;
+    if (nseg < 1) nseg = 1;
+    int seg_rows = ((h + nseg - 1) / nseg + 15) / 16 * 16;
+    nseg = (h + seg_rows - 1) / seg_rows;
+    (void)DELTA;
+    const int nwaves = nstrips * nseg;
+    hipLaunchKernelGGL((bx_vert_kernel<NB, P, NT>), dim3((nwaves + 3) / 4), dim3(256), 0, st, in, out, h, pitch, r, s_band, mul, seg_rows, nstrips, nwaves);
+    return hipGetLastError();
+}
+
+template <int NB, int NT>
+hipError_t bx_launch_vert_p(hipStream_t st, const uint8_t* in, uint8_t* out, int h, int pitch, int r, int passes, int s_band, uint32_t mul, int num_cus)
+{
+    switch (passes) {
+    case 1: return bx_launch_vert<NB, 1, NT>(st, in, out, h, pitch, r, s_band, mul, num_cus);
+    case 2: return bx_launch_vert<NB, 2, NT>(st, in, out, h, pitch, r, s_band, mul, num_cus);
+    default: return bx_launch_vert<NB, 3, NT>(st, in, out, h, pitch, r, s_band, mul, num_cus);
+    }
+}
+
+}  // namespace
+
+hipError_t bx_vertical(hipStream_t st, const uint8_t* in, uint8_t* out, int h, int pitch, int r, int passes, int num_cus, bool* ran)
+{
+    *ran = false;
+    int s_band = 0;
+    uint32_t mul = 0;
+    if (passes < 1 || passes > 3 || !bx_constants(r, &s_band, &mul)) return hipSuccess;
+    const int nb = r <= 24 ? 1 : r <= 56 ? 2 : 0;
+    if (!nb) return hipSuccess;
+    const int delta = 32 * nb - 8;
+    if ((pitch & 3) || (reinterpret_cast<uintptr_t>(in) & 3) || (reinterpret_cast<uintptr_t>(out) & 3)) return hipSuccess;
+    if (h < passes * delta + 32 || static_cast<long long>(h) * pitch >= (1ll << 31)) return hipSuccess;
+    *ran = true;
+    // narrow images: 64-byte strips give twice the waves
+    const bool narrow = pitch < 128 * 2 * num_cus;
+    if (nb == 1) return narrow ? bx_launch_vert_p<1, 4>(st, in, out, h, pitch, r, passes, s_band, mul, num_cus) : bx_launch_vert_p<1, 8>(st, in, out, h, pitch, r, passes, s_band, mul, num_cus);
+    return narrow ? bx_launch_vert_p<2, 4>(st, in, out, h, pitch, r, passes, s_band, mul, num_cus) : bx_launch_vert_p<2, 8>(st, in, out, h, pitch, r, passes, s_band, mul, num_cus);
+}
+
+size_t bx_horizontal_scratch(int, int, int, int, int) { return 0; }
+hipError_t bx_horizontal(hipStream_t, const uint8_t*, uint8_t*, uint8_t*, int, int, int, int, int, int, bool* ran)
+{
+    *ran = false;
+    return hipSuccess;
+}
+
+}  // namespace blur_amd

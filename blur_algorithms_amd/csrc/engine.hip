@@ -35,6 +35,7 @@
 #include "mx_registry.hpp"
 #define BLUR_FX_QUIRK_KERNELS
 #include "fx_registry.hpp"
+#include "bx_box.hpp"
 #include "wr_registry.hpp"
 
 using namespace blur_amd;
@@ -2017,6 +2018,13 @@ int blur_interleave_bgr_f32_u8_dev(blur_ctx* ctx, const float* d_planes, uint8_t
     return BLUR_OK;
 }
 
+// BLUR_BOX_NO_MFMA=1 (developer switch): the accumulator kernels only
+static bool box_no_mfma()
+{
+    static const bool off = [] { const char* e = getenv("BLUR_BOX_NO_MFMA"); return e && *e && *e != '0'; }();
+    return off;
+}
+
 int blur_fastboxblur_u8_dev(blur_ctx* ctx, uint8_t* d_inout, int w, int h, int channels, int ksize, int passes)
 {
     if (!ctx) return BLUR_ERR_INVALID;
@@ -2069,7 +2077,23 @@ int blur_fastboxblur_u8_dev(blur_ctx* ctx, uint8_t* d_inout, int w, int h, int c
     } else {
         for (int p = 0; p < passes; ++p) sweep(h, w, static_cast<size_t>(w) * channels, static_cast<size_t>(channels));
     }
-    if ((static_cast<size_t>(w) * channels) % 4 == 0) {
+    // vertical sweeps: up to three at a time in one launch on the integer matrix cores (bx_box.hip) where that kernel applies
+    int vdone = 0;
+    if (!box_no_mfma()) {
+        int r = (ksize - 1) / 2;
+        if (r > h - 1) r = h - 1;
+        while (vdone < passes && r > 0) {
+            const int now = std::min(3, passes - vdone);
+            bool ran = false;
+            HIP_TRY(ctx, bx_vertical(ctx->stream, a, b, h, static_cast<int>(static_cast<size_t>(w) * channels), r, now, ctx->num_cus, &ran));
+            if (!ran) break;
+            std::swap(a, b);
+            vdone += now;
+        }
+        if (r == 0) vdone = passes;            // a box of one row
+    }
+    if (vdone == passes) {
+    } else if ((static_cast<size_t>(w) * channels) % 4 == 0) {
         const int pitch4 = static_cast<int>(static_cast<size_t>(w) * channels / 4);
         int r = (ksize - 1) / 2;
         if (r > h - 1) r = h - 1;
@@ -2078,12 +2102,12 @@ int blur_fastboxblur_u8_dev(blur_ctx* ctx, uint8_t* d_inout, int w, int h, int c
         const int seg_len = (h + nseg - 1) / nseg;
         nseg = (h + seg_len - 1) / seg_len;
         const long long items = static_cast<long long>(pitch4) * nseg;
-        for (int p = 0; p < passes; ++p) {
+        for (int p = vdone; p < passes; ++p) {
             hipLaunchKernelGGL(boxcol4_kernel, dim3(static_cast<unsigned>((items + 255) / 256)), dim3(256), 0, ctx->stream, a, b, h, pitch4, r, seg_len, nseg);
             std::swap(a, b);
         }
     } else {
-        for (int p = 0; p < passes; ++p) sweep(w, h, static_cast<size_t>(channels), static_cast<size_t>(w) * channels);
+        for (int p = vdone; p < passes; ++p) sweep(w, h, static_cast<size_t>(channels), static_cast<size_t>(w) * channels);
     }
     HIP_TRY(ctx, hipGetLastError());
     if (a != d_inout) HIP_TRY(ctx, hipMemcpyAsync(d_inout, a, bytes, hipMemcpyDeviceToDevice, ctx->stream));
