@@ -23,6 +23,7 @@
 // kernel lays out beside the image first; the sweeps' intermediate values at positions outside the image are then the mirrored
 // intermediate values, as the oracle's per-sweep reflect requires.
 #include "bx_box.hpp"
+#include <algorithm>
 
 namespace blur_amd {
 namespace {
@@ -232,6 +233,214 @@ hipError_t bx_launch_vert_p(hipStream_t st, const uint8_t* in, uint8_t* out, int
     }
 }
 
+// ---- horizontal ----------------------------------------------------------------------------------------------------------
+// The same pipeline along the rows of interleaved pixels: positions are BYTES of a row, the band has its taps on every C-th byte
+// (reach C r), a wave owns NT groups of 16 rows (lane n = row) and a segment of the row.  Lane group q loads 16 bytes (dwordx4) at
+// byte 64 b + 16 q of the row for the four steps of block b; a 4 x 4 transpose of dwords across the four lane groups (two
+// v_permlane32_swap + two v_permlane16_swap) turns them into "dword q of the 16 bytes of step 4 b + j" in register j, the window
+// dword of that step.  Stores take the same road back, four steps at a time.  Bytes left of the row and right of it come from
+// `margins`: per row the mirrored pixels left of the row followed by its first 16 bytes, then its last 16 bytes followed by the
+// mirrored pixels right of it (bx_margins_kernel), so that a 16-byte group that leaves the row on either side is one load too.
+struct BxHorzGeom {
+    int h, pitch, C, r;
+    int seg_bytes, nseg, ngroups;     // segment length (multiple of 64), segments per row, groups of NT * 16 rows
+    int ml, mr, mpitch;               // margin bytes left / right of the row, bytes of margins per row (ml + 16 + 16 + mr)
+};
+
+__global__ __launch_bounds__(256) void bx_margins_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ margins, BxHorzGeom g)
+{
+    const int w = g.pitch / g.C;
+    const long long total = static_cast<long long>(g.h) * g.mpitch;
+    for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long long>(gridDim.x) * 256) {
+        const int row = static_cast<int>(i / g.mpitch), k = static_cast<int>(i - static_cast<long long>(row) * g.mpitch);
+        const int pos = k < g.ml + 16 ? k - g.ml : g.pitch - 16 + (k - g.ml - 16);          // byte position in the row
+        int x = pos >= 0 ? pos / g.C : -((-pos + g.C - 1) / g.C);
+        const int c = pos - x * g.C;
+        if (w > 1) {                                                                        // reflect-101, as often as it takes
+            const int m2 = 2 * (w - 1);
+            x %= m2;
+            if (x < 0) x += m2;
+            if (x >= w) x = m2 - x;
+        } else {
+            x = 0;
+        }
+        margins[i] = in[static_cast<size_t>(row) * g.pitch + x * g.C + c];
+    }
+}
+
+__device__ __forceinline__ void bx_transpose_groups(uint32_t (&x)[4])
+{
+    typedef uint32_t u2 __attribute__((ext_vector_type(2)));
+    u2 t;
+    t = __builtin_amdgcn_permlane32_swap(x[0], x[2], false, false); x[0] = t[0]; x[2] = t[1];
+    t = __builtin_amdgcn_permlane32_swap(x[1], x[3], false, false); x[1] = t[0]; x[3] = t[1];
+    t = __builtin_amdgcn_permlane16_swap(x[0], x[1], false, false); x[0] = t[0]; x[1] = t[1];
+    t = __builtin_amdgcn_permlane16_swap(x[2], x[3], false, false); x[2] = t[0]; x[3] = t[1];
+}
+
+template <int NB, int P, int NT>
+__global__ __launch_bounds__(256) void bx_horz_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const uint8_t* __restrict__ margins, BxHorzGeom g,
+                                                      int s_band, uint32_t mul, int nwaves)
+{
+    constexpr int W = 4 * NB, DELTA = 32 * NB - 8, FILL = (P * (W - 1) + 3) / 4 * 4;       // whole blocks of four steps
+    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (wid >= nwaves) return;
+    const int l = threadIdx.x & 63, n = l & 15, q = l >> 4;
+    const int grp = wid % g.ngroups, seg = wid / g.ngroups;
+    const int xs = seg * g.seg_bytes, xe = min(g.pitch, xs + g.seg_bytes);
+    const int nblk = FILL / 4 + (xe - xs + 63) / 64;
+    // sweep a's tile of step s covers bytes X0 - a DELTA + 16 s ..; the last sweep's tile of step FILL starts at xs
+    const int X0 = xs + P * DELTA - 16 * FILL;
+    const uint32_t obytes = static_cast<uint32_t>(g.h) * static_cast<uint32_t>(g.pitch);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out, 0, obytes, kRsrcWord3);
+
+    v4i band[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) band[u] = bx_band<NB>(u, n, q, g.r, g.C, s_band);
+    const int nt = 2 * g.r + 1, bias_last = s_band * (128 * nt + g.r), bias_mid = s_band * (256 * nt + g.r);
+    const v4i cin_last = { bias_last, bias_last, bias_last, bias_last }, cin_mid = { bias_mid, bias_mid, bias_mid, bias_mid };
+
+    const uint8_t* irow[NT];
+    const uint8_t* mrow[NT];
+    uint32_t orow[NT];
+    bool rok[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int row = (grp * NT + t) * 16 + n;
+        rok[t] = row < g.h;
+        const int rc = rok[t] ? row : g.h - 1;
+        irow[t] = in + static_cast<size_t>(rc) * g.pitch;
+        mrow[t] = margins + static_cast<size_t>(rc) * g.mpitch;
+        orow[t] = static_cast<uint32_t>(rc) * static_cast<uint32_t>(g.pitch);
+    }
+
+    uint32_t win[P][NT][W];
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int d = 0; d < W; ++d) win[a][t][d] = 0;
+
+    u4 ld[2][NT];
+    auto issue = [&](int b, u4 (&dst)[NT]) __attribute__((always_inline)) {
+        const int pos = X0 + 64 * b + 16 * q;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const uint8_t* src = pos < 0 ? mrow[t] + (pos + g.ml) : pos + 16 > g.pitch ? mrow[t] + (g.ml + 16 + pos - (g.pitch - 16)) : irow[t] + pos;
+            dst[t] = *reinterpret_cast<const u4*>(src);
+        }
+    };
+    issue(0, ld[0]);
+    if (nblk > 1) issue(1, ld[1]);
+
+    for (int b0 = 0; b0 < nblk; b0 += 2 * NB) {
+#pragma unroll
+        for (int bb = 0; bb < 2 * NB; ++bb) {
+            const int b = b0 + bb;
+            if (b >= nblk) break;
+            u4 (&cur)[NT] = ld[bb & 1];
+            uint32_t x[NT][4], y[NT][4];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[t][j] = cur[t][j];
+                bx_transpose_groups(x[t]);
+            }
+            if (b + 2 < nblk) issue(b + 2, cur);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int slot = (4 * bb + j) % W;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    win[0][t][slot] = x[t][j] ^ 0x80808080u;
+#pragma unroll
+                    for (int a = 0; a < P; ++a) {
+                        v4i d = a + 1 < P ? cin_mid : cin_last;
+#pragma unroll
+                        for (int G = 0; G < NB; ++G) {
+                            const v4i bop = { static_cast<int>(win[a][t][4 * G]), static_cast<int>(win[a][t][4 * G + 1]), static_cast<int>(win[a][t][4 * G + 2]),
+                                              static_cast<int>(win[a][t][4 * G + 3]) };
+                            d = __builtin_amdgcn_mfma_i32_16x16x64_i8(band[(slot - 4 * G + W) % W], bop, d, 0, 0, 0);
+                        }
+                        const uint32_t pk = bx_pack(d, mul);
+                        if (a + 1 < P) win[a + 1][t][slot] = pk; else y[t][j] = pk;
+                    }
+                }
+            }
+            if (4 * b >= FILL) {
+                const int pos = xs + 64 * (b - FILL / 4) + 16 * q;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    bx_transpose_groups(y[t]);
+                    if (pos + 16 <= xe) {
+                        const u4 wv = { y[t][0], y[t][1], y[t][2], y[t][3] };
+                        __builtin_amdgcn_raw_buffer_store_b128(wv, rout, rok[t] ? orow[t] + pos : kDropped, 0, 0);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            __builtin_amdgcn_raw_buffer_store_b32(y[t][k], rout, (rok[t] && pos + 4 * k + 4 <= xe) ? orow[t] + pos + 4 * k : kDropped, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NB> constexpr int bx_horz_fill(int P) { return (P * (4 * NB - 1) + 3) / 4 * 4; }
+
+template <int NB, int P, int NT>
+hipError_t bx_launch_horz(hipStream_t st, const uint8_t* in, uint8_t* out, uint8_t* margins, BxHorzGeom g, int s_band, uint32_t mul, int num_cus)
+{
+    constexpr int FILL = bx_horz_fill<NB>(P);
+    g.ngroups = (g.h + 16 * NT - 1) / (16 * NT);
+    // segments: enough waves for two per SIMD, but none shorter than four times what it takes to fill its pipeline
+    int nseg = (8 * num_cus + g.ngroups - 1) / g.ngroups;
+    const int most = g.pitch / (4 * 16 * FILL);
+    if (nseg > most) nseg = most;
+    if (nseg < 1) nseg = 1;
+    g.seg_bytes = ((g.pitch + nseg - 1) / nseg + 63) / 64 * 64;
+    g.nseg = (g.pitch + g.seg_bytes - 1) / g.seg_bytes;
+    const long long mtotal = static_cast<long long>(g.h) * g.mpitch;
+    hipLaunchKernelGGL(bx_margins_kernel, dim3(static_cast<unsigned>(std::min<long long>((mtotal + 255) / 256, 16 * 1024))), dim3(256), 0, st, in, margins, g);
+    const int nwaves = g.ngroups * g.nseg;
+    hipLaunchKernelGGL((bx_horz_kernel<NB, P, NT>), dim3((nwaves + 3) / 4), dim3(256), 0, st, in, out, margins, g, s_band, mul, nwaves);
+    return hipGetLastError();
+}
+
+template <int NB, int NT>
+hipError_t bx_launch_horz_p(hipStream_t st, const uint8_t* in, uint8_t* out, uint8_t* margins, BxHorzGeom g, int passes, int s_band, uint32_t mul, int num_cus)
+{
+    switch (passes) {
+    case 1: return bx_launch_horz<NB, 1, NT>(st, in, out, margins, g, s_band, mul, num_cus);
+    case 2: return bx_launch_horz<NB, 2, NT>(st, in, out, margins, g, s_band, mul, num_cus);
+    default: return bx_launch_horz<NB, 3, NT>(st, in, out, margins, g, s_band, mul, num_cus);
+    }
+}
+
+// window blocks of 64 bytes for a reach of C r bytes; 0: wider than the instantiated kernels
+int bx_horz_blocks(int C, int r)
+{
+    for (int nb = 1; nb <= 4; ++nb)
+        if (C * r <= 32 * nb - 8) return nb;
+    return 0;
+}
+
+bool bx_horz_geom(int h, int w, int C, int r, int passes, BxHorzGeom* g)
+{
+    const int nb = bx_horz_blocks(C, r);
+    if (!nb || passes < 1 || passes > 3 || !(C == 1 || C == 3 || C == 4)) return false;
+    const long long pitch = static_cast<long long>(w) * C;
+    if ((pitch & 3) || pitch < 128 || pitch * h >= (1ll << 31)) return false;
+    const int fill = (passes * (4 * nb - 1) + 3) / 4 * 4, delta = 32 * nb - 8;
+    g->h = h; g->pitch = static_cast<int>(pitch); g->C = C; g->r = r;
+    g->ml = 16 * fill - passes * delta;                 // -X0 of the first segment
+    g->mr = passes * delta + 16 + 64 + 16;              // the last segment's last block ends at most this far past the row
+    g->mpitch = g->ml + 16 + 16 + g->mr;
+    g->seg_bytes = g->nseg = g->ngroups = 0;
+    return true;
+}
+
 }  // namespace
 
 hipError_t bx_vertical(hipStream_t st, const uint8_t* in, uint8_t* out, int h, int pitch, int r, int passes, int num_cus, bool* ran)
@@ -252,11 +461,28 @@ hipError_t bx_vertical(hipStream_t st, const uint8_t* in, uint8_t* out, int h, i
     return narrow ? bx_launch_vert_p<2, 4>(st, in, out, h, pitch, r, passes, s_band, mul, num_cus) : bx_launch_vert_p<2, 8>(st, in, out, h, pitch, r, passes, s_band, mul, num_cus);
 }
 
-size_t bx_horizontal_scratch(int, int, int, int, int) { return 0; }
-hipError_t bx_horizontal(hipStream_t, const uint8_t*, uint8_t*, uint8_t*, int, int, int, int, int, int, bool* ran)
+size_t bx_horizontal_scratch(int h, int w, int C, int r, int passes)
+{
+    BxHorzGeom g;
+    if (!bx_horz_geom(h, w, C, r, passes, &g)) return 0;
+    return static_cast<size_t>(h) * g.mpitch + 64;
+}
+
+hipError_t bx_horizontal(hipStream_t st, const uint8_t* in, uint8_t* out, uint8_t* margins, int h, int w, int C, int r, int passes, int num_cus, bool* ran)
 {
     *ran = false;
-    return hipSuccess;
+    int s_band = 0;
+    uint32_t mul = 0;
+    BxHorzGeom g;
+    if (!margins || !bx_constants(r, &s_band, &mul) || !bx_horz_geom(h, w, C, r, passes, &g)) return hipSuccess;
+    if ((reinterpret_cast<uintptr_t>(in) & 3) || (reinterpret_cast<uintptr_t>(out) & 3) || (reinterpret_cast<uintptr_t>(margins) & 3)) return hipSuccess;
+    *ran = true;
+    switch (bx_horz_blocks(C, r)) {
+    case 1: return bx_launch_horz_p<1, 1>(st, in, out, margins, g, passes, s_band, mul, num_cus);
+    case 2: return bx_launch_horz_p<2, 1>(st, in, out, margins, g, passes, s_band, mul, num_cus);
+    case 3: return bx_launch_horz_p<3, 1>(st, in, out, margins, g, passes, s_band, mul, num_cus);
+    default: return bx_launch_horz_p<4, 1>(st, in, out, margins, g, passes, s_band, mul, num_cus);
+    }
 }
 
 }  // namespace blur_amd

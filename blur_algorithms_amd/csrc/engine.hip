@@ -2032,12 +2032,16 @@ int blur_fastboxblur_u8_dev(blur_ctx* ctx, uint8_t* d_inout, int w, int h, int c
         return fail(ctx, BLUR_ERR_INVALID, "fastboxblur: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bytes = static_cast<size_t>(w) * h * channels;
-    if (ctx->box_bytes < bytes) {
+    // the second image, and behind it the mirrored row margins of the matrix-core horizontal kernel (bx_box.hip)
+    const size_t margins_at = (bytes + 255) & ~static_cast<size_t>(255);
+    const size_t margins_bytes = bx_horizontal_scratch(h, w, channels, std::min((ksize - 1) / 2, w - 1), std::min(passes, 3));
+    if (ctx->box_bytes < margins_at + margins_bytes) {
         if (ctx->box_tmp) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->box_tmp)); ctx->box_tmp = nullptr; ctx->box_bytes = 0; }
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->box_tmp), bytes));
-        ctx->box_bytes = bytes;
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->box_tmp), margins_at + margins_bytes));
+        ctx->box_bytes = margins_at + margins_bytes;
     }
     uint8_t *a = d_inout, *b = ctx->box_tmp;
+    uint8_t* margins = margins_bytes ? ctx->box_tmp + margins_at : nullptr;
     auto sweep = [&](int nlines, int n, size_t lstride, size_t xstride) {
         int r = (ksize - 1) / 2;
         if (r > n - 1) r = n - 1;
@@ -2055,27 +2059,42 @@ int blur_fastboxblur_u8_dev(blur_ctx* ctx, uint8_t* d_inout, int w, int h, int c
     if (r_row > w - 1) r_row = w - 1;
     const int off0 = ((r_row + 2) * channels + 4 + 15) & ~15;                       // whole aligned dwords left of pixel -(r+1)
     const int buf_bytes = (off0 + (w + r_row + 8) * channels + 16 + 15) & ~15;       // ... and right of pixel w+r+3
-    if (passes > 0 && (channels == 1 || channels == 3 || channels == 4) && 2 * static_cast<size_t>(buf_bytes) <= kLdsLimit) {
+    // horizontal sweeps: up to three at a time in one launch on the integer matrix cores where that kernel applies
+    int hdone = 0;
+    if (!box_no_mfma() && r_row > 0) {
+        while (hdone < passes) {
+            const int now = std::min(3, passes - hdone);
+            bool ran = false;
+            HIP_TRY(ctx, bx_horizontal(ctx->stream, a, b, margins, h, w, channels, r_row, now, ctx->num_cus, &ran));
+            if (!ran) break;
+            std::swap(a, b);
+            hdone += now;
+        }
+    }
+    if (r_row == 0) hdone = passes;               // a box of one pixel
+    const int hleft = passes - hdone;
+    if (hleft == 0) {
+    } else if ((channels == 1 || channels == 3 || channels == 4) && 2 * static_cast<size_t>(buf_bytes) <= kLdsLimit) {
         const int gpt = ((w + 3) / 4 + 255) / 256;
         const size_t lds = 2 * static_cast<size_t>(buf_bytes);
         auto launch = [&](auto kern) -> int {
             if (int rc = set_lds(ctx, kern, lds)) return rc;
-            hipLaunchKernelGGL(kern, dim3(h), dim3(256), lds, ctx->stream, a, b, w, r_row, passes, gpt, off0, buf_bytes);
+            hipLaunchKernelGGL(kern, dim3(h), dim3(256), lds, ctx->stream, a, b, w, r_row, hleft, gpt, off0, buf_bytes);
             return BLUR_OK;
         };
         int rc = channels == 1 ? launch(boxrow4_kernel<1>) : channels == 3 ? launch(boxrow4_kernel<3>) : launch(boxrow4_kernel<4>);
         if (rc) return rc;
         std::swap(a, b);
-    } else if (passes > 0 && row_lds <= kLdsLimit) {
+    } else if (row_lds <= kLdsLimit) {
         if (int rc = set_lds(ctx, boxrow_kernel, row_lds)) return rc;
         int r = (ksize - 1) / 2;
         if (r > w - 1) r = w - 1;
         const int nseg = std::max(1, 256 / channels);
         const int seg_len = (w + nseg - 1) / nseg;
-        hipLaunchKernelGGL(boxrow_kernel, dim3(h), dim3(256), row_lds, ctx->stream, a, b, w, channels, r, passes, seg_len, nseg);
+        hipLaunchKernelGGL(boxrow_kernel, dim3(h), dim3(256), row_lds, ctx->stream, a, b, w, channels, r, hleft, seg_len, nseg);
         std::swap(a, b);
     } else {
-        for (int p = 0; p < passes; ++p) sweep(h, w, static_cast<size_t>(w) * channels, static_cast<size_t>(channels));
+        for (int p = 0; p < hleft; ++p) sweep(h, w, static_cast<size_t>(w) * channels, static_cast<size_t>(channels));
     }
     // vertical sweeps: up to three at a time in one launch on the integer matrix cores (bx_box.hip) where that kernel applies
     int vdone = 0;
