@@ -24,6 +24,7 @@
 // intermediate values, as the oracle's per-sweep reflect requires.
 #include "bx_box.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace blur_amd {
 namespace {
@@ -73,6 +74,7 @@ __device__ __forceinline__ uint32_t bx_pack(v4i d, uint32_t mul)
 template <int NB> __device__ __forceinline__ v4i bx_band(int u, int m, int q, int r, int stride, int s)
 {
     constexpr int W = 4 * NB, DELTA = 32 * NB - 8;
+    const int dm = stride == 3 ? 171 : 1, ds = stride == 3 ? 9 : stride == 4 ? 2 : 0;
     v4i a;
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
@@ -81,7 +83,8 @@ template <int NB> __device__ __forceinline__ v4i bx_band(int u, int m, int q, in
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int off = 16 * t + 4 * q + i - DELTA - m, ao = off < 0 ? -off : off;
-            if (ao <= stride * r && ao % stride == 0) word |= static_cast<uint32_t>(s) << (8 * i);
+            const int rem = ao - ((ao * dm) >> ds) * stride;      // ao % stride without a division (stride 1, 3 or 4; ao < 256)
+            word |= (ao <= stride * r && rem == 0 ? static_cast<uint32_t>(s) : 0u) << (8 * i);
         }
         a[d] = static_cast<int>(word);
     }
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void bx_vert_kernel(const uint8_t* __restrict_
 {
     constexpr int W = 4 * NB, DELTA = 32 * NB - 8, FILL = P * (W - 1);
     static_assert(NT % 4 == 0, "dwordx4 loads");
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * 4 + (threadIdx.x >> 6)));      // wave-uniform: scalar branches below
     if (wid >= nwaves) return;
     const int l = threadIdx.x & 63, n = l & 15, q = l >> 4, qd = n >> 2, p = n & 3;
     const int strip = wid % nstrips, seg = wid / nstrips;
@@ -191,6 +194,13 @@ __global__ __launch_bounds__(256) void bx_vert_kernel(const uint8_t* __restrict_
     }
 }
 
+// developer knobs (tools/bx_dev.py sweeps them): BLUR_BX_VSEG / BLUR_BX_HSEG = segments per column strip / per row, BLUR_BX_VNT = 4 | 8
+int bx_env(const char* name)
+{
+    const char* e = getenv(name);
+    return e && *e ? atoi(e) : 0;
+}
+
 // band entry and multiplier for a box of n = 2 r + 1 taps (see the header); false: outside the exact range
 bool bx_constants(int r, int* s_band, uint32_t* mul)
 {
@@ -207,17 +217,19 @@ bool bx_constants(int r, int* s_band, uint32_t* mul)
 template <int NB, int P, int NT>
 hipError_t bx_launch_vert(hipStream_t st, const uint8_t* in, uint8_t* out, int h, int pitch, int r, int s_band, uint32_t mul, int num_cus)
 {
-    constexpr int DELTA = 32 * NB - 8, W = 4 * NB;
+    constexpr int W = 4 * NB;
     const int nstrips = (pitch + 16 * NT - 1) / (16 * NT);
-    // segments: as few as give every SIMD a wave or two (each pays P (W - 1) steps to fill its pipeline)
+    // segments: four waves per SIMD in all (measured at 8K, k = 41, P = 3: 82 / 62 / 53 / 54 / 64 us with 3 / 6 / 10 / 14 / 30 segments
+    // of 360 strips -- the walk is a chain of dependent matrix and vector instructions and lives on other waves' work), but no
+    // segment shorter than twice the rows it takes to fill its pipeline
     const int fill_rows = 16 * P * (W - 1);
-    int nseg = (8 * num_cus + nstrips - 1) / nstrips;
-    const int most = (h + 4 * fill_rows - 1) / (4 * fill_rows) > 0 ? h / (2 * fill_rows) : 1;
+    int nseg = (16 * num_cus + nstrips / 2) / nstrips;
+    const int most = h / (2 * fill_rows);
     if (nseg > most) nseg = most;
+    if (bx_env("BLUR_BX_VSEG") > 0) nseg = bx_env("BLUR_BX_VSEG");
     if (nseg < 1) nseg = 1;
     int seg_rows = ((h + nseg - 1) / nseg + 15) / 16 * 16;
     nseg = (h + seg_rows - 1) / seg_rows;
-    (void)DELTA;
     const int nwaves = nstrips * nseg;
     hipLaunchKernelGGL((bx_vert_kernel<NB, P, NT>), dim3((nwaves + 3) / 4), dim3(256), 0, st, in, out, h, pitch, r, s_band, mul, seg_rows, nstrips, nwaves);
     return hipGetLastError();
@@ -249,23 +261,22 @@ struct BxHorzGeom {
 
 __global__ __launch_bounds__(256) void bx_margins_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ margins, BxHorzGeom g)
 {
+    // one thread per margin byte of row blockIdx.y; positions are taken relative to the row's end they belong to, so every
+    // division is of a small number by C = 1, 3 or 4 (multiply and shift)
+    const int k = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    if (k >= g.mpitch) return;
     const int w = g.pitch / g.C;
-    const long long total = static_cast<long long>(g.h) * g.mpitch;
-    for (long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x; i < total; i += static_cast<long long>(gridDim.x) * 256) {
-        const int row = static_cast<int>(i / g.mpitch), k = static_cast<int>(i - static_cast<long long>(row) * g.mpitch);
-        const int pos = k < g.ml + 16 ? k - g.ml : g.pitch - 16 + (k - g.ml - 16);          // byte position in the row
-        int x = pos >= 0 ? pos / g.C : -((-pos + g.C - 1) / g.C);
-        const int c = pos - x * g.C;
-        if (w > 1) {                                                                        // reflect-101, as often as it takes
-            const int m2 = 2 * (w - 1);
-            x %= m2;
-            if (x < 0) x += m2;
-            if (x >= w) x = m2 - x;
-        } else {
-            x = 0;
-        }
-        margins[i] = in[static_cast<size_t>(row) * g.pitch + x * g.C + c];
+    const bool left = k < g.ml + 16;
+    const int rel = (left ? k - g.ml : k - g.ml - 32) + g.C * 4096;            // byte offset from pixel 0 / from pixel w, made positive
+    const int xq = g.C == 3 ? static_cast<int>((static_cast<uint32_t>(rel) * 43691u) >> 17) : g.C == 4 ? rel >> 2 : rel;      // rel < 2^16
+    const int c = rel - xq * g.C;
+    int x = xq - 4096 + (left ? 0 : w);
+    for (int it = 0; it < 64 && (x < 0 || x >= w); ++it) {                      // reflect-101, as often as it takes
+        x = x < 0 ? -x : x;
+        x = x >= w ? 2 * (w - 1) - x : x;
     }
+    x = w > 1 ? x : 0;
+    margins[static_cast<size_t>(row) * g.mpitch + k] = in[static_cast<size_t>(row) * g.pitch + x * g.C + c];
 }
 
 __device__ __forceinline__ void bx_transpose_groups(uint32_t (&x)[4])
@@ -283,7 +294,7 @@ __global__ __launch_bounds__(256) void bx_horz_kernel(const uint8_t* __restrict_
                                                       int s_band, uint32_t mul, int nwaves)
 {
     constexpr int W = 4 * NB, DELTA = 32 * NB - 8, FILL = (P * (W - 1) + 3) / 4 * 4;       // whole blocks of four steps
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * 4 + (threadIdx.x >> 6)));      // wave-uniform: scalar branches below
     if (wid >= nwaves) return;
     const int l = threadIdx.x & 63, n = l & 15, q = l >> 4;
     const int grp = wid % g.ngroups, seg = wid / g.ngroups;
@@ -394,15 +405,16 @@ hipError_t bx_launch_horz(hipStream_t st, const uint8_t* in, uint8_t* out, uint8
 {
     constexpr int FILL = bx_horz_fill<NB>(P);
     g.ngroups = (g.h + 16 * NT - 1) / (16 * NT);
-    // segments: enough waves for two per SIMD, but none shorter than four times what it takes to fill its pipeline
-    int nseg = (8 * num_cus + g.ngroups - 1) / g.ngroups;
-    const int most = g.pitch / (4 * 16 * FILL);
+    // segments: four waves per SIMD in all (8K, k = 41, P = 3: 100 / 75 / 70 / 69 / 80 / 86 us with 4 / 6 / 10 / 15 / 20 / 30 segments of
+    // 270 row groups), none shorter than twice the bytes it takes to fill its pipeline
+    int nseg = (16 * num_cus + g.ngroups / 2) / g.ngroups;
+    const int most = g.pitch / (2 * 16 * FILL);
     if (nseg > most) nseg = most;
+    if (bx_env("BLUR_BX_HSEG") > 0) nseg = bx_env("BLUR_BX_HSEG");
     if (nseg < 1) nseg = 1;
     g.seg_bytes = ((g.pitch + nseg - 1) / nseg + 63) / 64 * 64;
     g.nseg = (g.pitch + g.seg_bytes - 1) / g.seg_bytes;
-    const long long mtotal = static_cast<long long>(g.h) * g.mpitch;
-    hipLaunchKernelGGL(bx_margins_kernel, dim3(static_cast<unsigned>(std::min<long long>((mtotal + 255) / 256, 16 * 1024))), dim3(256), 0, st, in, margins, g);
+    hipLaunchKernelGGL(bx_margins_kernel, dim3((g.mpitch + 255) / 256, g.h), dim3(256), 0, st, in, margins, g);
     const int nwaves = g.ngroups * g.nseg;
     hipLaunchKernelGGL((bx_horz_kernel<NB, P, NT>), dim3((nwaves + 3) / 4), dim3(256), 0, st, in, out, margins, g, s_band, mul, nwaves);
     return hipGetLastError();
@@ -456,7 +468,7 @@ hipError_t bx_vertical(hipStream_t st, const uint8_t* in, uint8_t* out, int h, i
     if (h < passes * delta + 32 || static_cast<long long>(h) * pitch >= (1ll << 31)) return hipSuccess;
     *ran = true;
     // narrow images: 64-byte strips give twice the waves
-    const bool narrow = pitch < 128 * 2 * num_cus;
+    const bool narrow = bx_env("BLUR_BX_VNT") ? bx_env("BLUR_BX_VNT") == 4 : pitch < 128 * 2 * num_cus;
     if (nb == 1) return narrow ? bx_launch_vert_p<1, 4>(st, in, out, h, pitch, r, passes, s_band, mul, num_cus) : bx_launch_vert_p<1, 8>(st, in, out, h, pitch, r, passes, s_band, mul, num_cus);
     return narrow ? bx_launch_vert_p<2, 4>(st, in, out, h, pitch, r, passes, s_band, mul, num_cus) : bx_launch_vert_p<2, 8>(st, in, out, h, pitch, r, passes, s_band, mul, num_cus);
 }

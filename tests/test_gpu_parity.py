@@ -406,6 +406,67 @@ def test_fastboxblur(ctx, w, h, ch, ksize, passes):
     assert np.array_equal(got, want)
 
 
+# shapes that run on the integer matrix cores (csrc/bx_box.hip): every window size of the horizontal kernel (reach C r <= 24, 56,
+# 88, 120 bytes) and of the vertical one (r <= 24, 56), 1 / 3 / 4 channels, more than three passes (two launches per direction),
+# row pitches that are not a multiple of 16 bytes, heights that are not a multiple of 16, and shapes where one direction falls back
+# to the accumulator kernels (box wider than the windows, too few rows for the pipeline, pitch not a multiple of 4)
+BX_SHAPES = [(640, 480, 3, 41, 3), (256, 300, 1, 9, 2), (128, 200, 4, 15, 1), (600, 900, 3, 65, 2), (1000, 700, 3, 49, 3), (512, 400, 3, 3, 3),
+             (512, 400, 3, 5, 4), (300, 333, 4, 11, 5), (644, 333, 3, 41, 3), (201, 257, 4, 21, 2), (700, 500, 3, 81, 3), (4096, 300, 1, 121, 2),
+             (640, 60, 3, 41, 3), (333, 517, 3, 41, 3), (2048, 200, 1, 49, 3), (700, 420, 3, 115, 2), (64, 200, 3, 7, 3), (44, 300, 3, 7, 3)]
+
+
+@pytest.mark.parametrize("w,h,ch,ksize,passes", BX_SHAPES)
+@pytest.mark.parametrize("kind", ["uniform", "binary"])
+def test_fastboxblur_on_the_matrix_cores(ctx, w, h, ch, ksize, passes, kind):
+    """bytes equal to oracle/boxblur_oracle.c; `binary` images (0 / 255) reach the largest sums the 24-bit multiply has to divide"""
+    torch = _torch()
+    from oracle import oracle as O
+    rng = np.random.default_rng(w * 7 + h)
+    img = rng.integers(0, 256, (h, w, ch), dtype=np.uint8) if kind == "uniform" else (rng.integers(0, 2, (h, w, ch)) * 255).astype(np.uint8)
+    want = O.fastboxblur_u8(img, ksize, passes)
+    got = ctx.fastboxblur(torch.from_numpy(img.copy()).cuda(), ksize, passes).cpu().numpy()
+    assert np.array_equal(got, want)
+
+
+def test_fastboxblur_every_box_width_and_extremes(ctx):
+    """every odd width 3 .. 129 on one image (all four window sizes of both kernels, the widths past them), then the images with
+    the largest and smallest sums: all 255, all 0, alternating columns, alternating rows"""
+    torch = _torch()
+    from oracle import oracle as O
+    img = np.random.default_rng(77).integers(0, 256, (260, 384, 3), dtype=np.uint8)
+    for k in range(3, 131, 2):
+        want = O.fastboxblur_u8(img, k, 2)
+        got = ctx.fastboxblur(torch.from_numpy(img.copy()).cuda(), k, 2).cpu().numpy()
+        assert np.array_equal(got, want), "box width %d" % k
+    x = np.arange(384)[None, :, None]
+    y = np.arange(260)[:, None, None]
+    for name, im in (("white", np.full((260, 384, 3), 255)), ("black", np.zeros((260, 384, 3))), ("columns", np.broadcast_to(255 * (x & 1), (260, 384, 3))),
+                     ("rows", np.broadcast_to(255 * (y & 1), (260, 384, 3)))):
+        im = np.ascontiguousarray(im).astype(np.uint8)
+        for k in (3, 41, 49, 79):
+            want = O.fastboxblur_u8(im, k, 3)
+            got = ctx.fastboxblur(torch.from_numpy(im.copy()).cuda(), k, 3).cpu().numpy()
+            assert np.array_equal(got, want), "%s, box width %d" % (name, k)
+
+
+def test_fastboxblur_writes_nothing_outside_the_image(ctx):
+    """in place on a buffer with guard bytes either side, at a 4-byte-aligned and at an odd offset (the odd one runs the accumulator
+    kernels: the matrix-core kernels want dword-aligned rows)"""
+    torch = _torch()
+    from oracle import oracle as O
+    rng = np.random.default_rng(5)
+    for (w, h, ch, k, p, shift) in ((640, 300, 3, 41, 3, 0), (644, 301, 3, 41, 3, 0), (400, 300, 4, 15, 2, 0), (640, 300, 3, 41, 3, 1)):
+        img = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+        n, guard = img.size, 4096
+        buf = torch.full((n + 2 * guard + 8,), 0xA5, dtype=torch.uint8, device="cuda")
+        view = buf[guard + shift:guard + shift + n].view(h, w, ch)
+        view.copy_(torch.from_numpy(img))
+        ctx.fastboxblur(view, k, p)
+        assert np.array_equal(view.cpu().numpy(), O.fastboxblur_u8(img, k, p))
+        red = torch.cat([buf[:guard + shift], buf[guard + shift + n:]])
+        assert int((red != 0xA5).sum()) == 0, "guard bytes overwritten"
+
+
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
