@@ -5,9 +5,8 @@
 // provided by the MI355X engine (flip_block on the host, fastboxblur on the GPU through
 // libblur_amd.so).  Use with  -I<repo>/include/compat -I<repo>/include.
 //
-// There is deliberately no pffft_pommier/pffft.h shim: pffft's per-line transform API would pin
-// the caller to one-line-at-a-time host round trips; the engine replaces the whole pffft_()
-// body instead (blur_amd.hpp: pffft_(Mat&, double)), see INTEGRATION.md.
+// The companion shim pffft_pommier/pffft.h is a host implementation of pffft's per-line interface; the
+// MI355X path replaces the whole pffft_() body instead (blur_amd.hpp: pffft_(Mat&, double)), see INTEGRATION.md.
 #pragma once
 #include "../../blur_amd.hpp"
 using blur_amd::compat::fastboxblur;

@@ -108,6 +108,17 @@ def test_fastboxblur_include_path_shim_compiles(tmp_path):
     assert subprocess.run([exe]).returncode == 0
 
 
+def test_pffft_include_path_shim(tmp_path):
+    """include/compat/pffft_pommier/pffft.h used as Source.cpp uses pffft (lines 477-566): ordered real transforms against a float64
+    DFT for a dozen valid lengths, the unscaled round trip, refused sizes, and one reflect-padded tile through forward -> the
+    pointwise rule of Source.cpp:414-427 -> backward against the direct convolution (tests/cpp/pffft_shim_check.cpp)"""
+    exe = str(tmp_path / "pffft_shim_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include", "compat"),
+                           os.path.join(ROOT, "tests", "cpp", "pffft_shim_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "pffft shim ok" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("mode", [["-fopenmp"], ["-DMYLOOP", "-pthread"], []])
 def test_cpp_header_with_reference_names(mode):
     """include/blur_amd.hpp under the reference's three hybrid_loop build modes (Utils.hpp:24-54): OpenMP, -DMYLOOP
