@@ -68,8 +68,8 @@ template <typename T> __device__ __forceinline__ float load_px(const T* p) { ret
 // ------------------------------------------------------------------------------------
 // row pass: one workgroup = rows (2q, 2q+1) of channel c
 // ------------------------------------------------------------------------------------
-template <typename InT, int CH>
-__global__ __launch_bounds__(kThreads) void rowpass_kernel(const InT* __restrict__ src, float* __restrict__ planes,
+template <typename InT, int CH, int T = kThreads>
+__global__ __launch_bounds__(T) void rowpass_kernel(const InT* __restrict__ src, float* __restrict__ planes,
                                                            int rows, int cols, int pad, DevPlan plan,
                                                            const float2* __restrict__ tw, const float* __restrict__ mperm)
 {
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kThreads) void rowpass_kernel(const InT* __restrict
     // unconditional loads (clamped index, value masked afterwards): a load under a branch costs one
     // memory round trip per iteration, unconditional ones overlap across the unrolled iterations
 #pragma unroll 8
-    for (int p = threadIdx.x; p < n; p += kThreads) {
+    for (int p = threadIdx.x; p < n; p += T) {
         const int x = reflect_src(p, pad, cols);
         const size_t xi = static_cast<size_t>(x >= 0 ? x : 0) * CH;
         const float a = load_px(row_a + xi), b = load_px(row_b + xi);
@@ -97,7 +97,7 @@ __global__ __launch_bounds__(kThreads) void rowpass_kernel(const InT* __restrict
 
     float* out_a = planes + (static_cast<size_t>(c) * rows + r0) * cols;
     float* out_b = out_a + cols;
-    for (int x = threadIdx.x; x < cols; x += kThreads) {
+    for (int x = threadIdx.x; x < cols; x += T) {
         const float2 v = z[phys(pad + x)];
         out_a[x] = v.x;
         if (two) out_b[x] = v.y;
@@ -109,8 +109,8 @@ __global__ __launch_bounds__(kThreads) void rowpass_kernel(const InT* __restrict
 // ------------------------------------------------------------------------------------
 __device__ __forceinline__ void store_out(float* p, float v) { *p = v; }
 
-template <typename OutT, int CH, int C>
-__global__ __launch_bounds__(kThreads) void colpass_kernel(const float* __restrict__ planes, OutT* __restrict__ dst,
+template <typename OutT, int CH, int C, int T = kThreads>
+__global__ __launch_bounds__(T) void colpass_kernel(const float* __restrict__ planes, OutT* __restrict__ dst,
                                                            int rows, int cols, int pad, DevPlan plan,
                                                            const float2* __restrict__ tw, const float* __restrict__ mperm)
 {
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(kThreads) void colpass_kernel(const float* __restri
         const float* plane = planes + static_cast<size_t>(c) * rows * cols;
         // gather the strip: position p of line l  <-  plane[reflect(p)][x0 + 2l, x0 + 2l + 1]
 #pragma unroll 4
-        for (int idx = threadIdx.x; idx < n * C; idx += kThreads) {
+        for (int idx = threadIdx.x; idx < n * C; idx += T) {
             const int p = idx / C, l = idx - p * C;
             const int r = reflect_src(p, pad, rows);
             const int col = x0 + 2 * l;
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(kThreads) void colpass_kernel(const float* __restri
 
         if constexpr (sizeof(OutT) == 1) {
             // interleave_BGR<uint8_t,float>: (uint8_t)(value + 0.5f)   Utils.hpp:189,204-206
-            for (int idx = threadIdx.x; idx < rows * C; idx += kThreads) {
+            for (int idx = threadIdx.x; idx < rows * C; idx += T) {
                 const int r = idx / C, l = idx - r * C;
                 const float2 v = z[l * zs + phys(pad + r)];
                 uint8_t* s = stage + (static_cast<size_t>(r) * G + 2 * l) * CH + c;
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(kThreads) void colpass_kernel(const float* __restri
                 s[CH] = static_cast<uint8_t>(static_cast<int>(v.y + 0.5f));
             }
         } else {
-            for (int idx = threadIdx.x; idx < rows * C; idx += kThreads) {
+            for (int idx = threadIdx.x; idx < rows * C; idx += T) {
                 const int r = idx / C, l = idx - r * C;
                 const float2 v = z[l * zs + phys(pad + r)];
                 const int col = x0 + 2 * l;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kThreads) void colpass_kernel(const float* __restri
 
     if constexpr (sizeof(OutT) == 1) {
         const int wbytes = (min(G, cols - x0)) * CH;      // valid bytes per row of the strip
-        for (int idx = threadIdx.x; idx < rows * G * CH; idx += kThreads) {
+        for (int idx = threadIdx.x; idx < rows * G * CH; idx += T) {
             const int r = idx / (G * CH), b = idx - r * (G * CH);
             if (b < wbytes) dst[(static_cast<size_t>(r) * cols + x0) * CH + b] = stage[idx];
         }
@@ -835,6 +835,19 @@ static size_t col_lds_bytes(int n, int C, int rows, int out_bytes_per_px)
     return static_cast<size_t>(C) * line_stride(n) * sizeof(float2) + (out_bytes_per_px ? static_cast<size_t>(rows) * 2 * C * out_bytes_per_px : 0) + 16;
 }
 
+// threads per workgroup of the run-time-planned kernels by the LDS a workgroup takes (BLUR_GENERIC_THREADS overrides: developer
+// knob).  Measured on single images of the reference's sweep (4000 x 6000 sigma 77.5 / 7600 x 11400 sigma 106.8; 256, 512, 1024
+// threads): column kernel 908 / 606 / 622 and 3517 / 2673 / 2694 us -- long lines leave room for one or two workgroups per CU and
+// four waves per CU hide nothing of the strip gather; row kernel 367 / 459 / 437 and 1641 / 1263 / 1210 us -- better only for the
+// longest lines.
+static int generic_threads(size_t lds, bool column_pass)
+{
+    static const int forced = [] { const char* e = getenv("BLUR_GENERIC_THREADS"); return e && *e ? atoi(e) : 0; }();
+    if (forced == 256 || forced == 512 || forced == 1024) return forced;
+    if (column_pass) return lds > 40 * 1024 ? 512 : 256;
+    return lds > 80 * 1024 ? 1024 : 256;
+}
+
 template <typename K> static int set_lds(blur_ctx* ctx, K kernel, size_t bytes)
 {
     if (bytes > 64 * 1024)
@@ -848,11 +861,21 @@ static int launch_rowpass(blur_ctx* ctx, const InT* src, float* planes, int rows
 {
     const size_t lds = row_lds_bytes(plan.dev.n);
     if (lds > kLdsLimit) return fail(ctx, BLUR_ERR_UNSUPPORTED, "row FFT length exceeds LDS capacity");
-    if (int rc = set_lds(ctx, rowpass_kernel<InT, CH>, lds)) return rc;
     const int grid = ((rows + 1) / 2) * CH;
+    // long lines leave room for one or two workgroups per CU only: four times the threads then (the passes are loops over
+    // butterflies with a barrier each, and 4 waves per CU hide nothing)
+    const int threads = generic_threads(lds, false);
     TimedLaunch t(ctx, 0);
-    hipLaunchKernelGGL((rowpass_kernel<InT, CH>), dim3(grid), dim3(kThreads), lds, ctx->stream,
-                       src, planes, rows, cols, pad, plan.dev, plan.d_tw, mperm);
+    if (threads == 1024) {
+        if (int rc = set_lds(ctx, rowpass_kernel<InT, CH, 1024>, lds)) return rc;
+        hipLaunchKernelGGL((rowpass_kernel<InT, CH, 1024>), dim3(grid), dim3(1024), lds, ctx->stream, src, planes, rows, cols, pad, plan.dev, plan.d_tw, mperm);
+    } else if (threads == 512) {
+        if (int rc = set_lds(ctx, rowpass_kernel<InT, CH, 512>, lds)) return rc;
+        hipLaunchKernelGGL((rowpass_kernel<InT, CH, 512>), dim3(grid), dim3(512), lds, ctx->stream, src, planes, rows, cols, pad, plan.dev, plan.d_tw, mperm);
+    } else {
+        if (int rc = set_lds(ctx, rowpass_kernel<InT, CH>, lds)) return rc;
+        hipLaunchKernelGGL((rowpass_kernel<InT, CH>), dim3(grid), dim3(kThreads), lds, ctx->stream, src, planes, rows, cols, pad, plan.dev, plan.d_tw, mperm);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return BLUR_OK;
 }
@@ -862,11 +885,19 @@ static int launch_colpass_c(blur_ctx* ctx, const float* planes, OutT* dst, int r
                             const DevicePlan& plan, const float* mperm)
 {
     const size_t lds = col_lds_bytes(plan.dev.n, C, rows, sizeof(OutT) == 1 ? CH : 0);
-    if (int rc = set_lds(ctx, colpass_kernel<OutT, CH, C>, lds)) return rc;
     const int grid = (cols + 2 * C - 1) / (2 * C);
+    const int threads = generic_threads(lds, true);
     TimedLaunch t(ctx, 1);
-    hipLaunchKernelGGL((colpass_kernel<OutT, CH, C>), dim3(grid), dim3(kThreads), lds, ctx->stream,
-                       planes, dst, rows, cols, pad, plan.dev, plan.d_tw, mperm);
+    if (threads == 1024) {
+        if (int rc = set_lds(ctx, colpass_kernel<OutT, CH, C, 1024>, lds)) return rc;
+        hipLaunchKernelGGL((colpass_kernel<OutT, CH, C, 1024>), dim3(grid), dim3(1024), lds, ctx->stream, planes, dst, rows, cols, pad, plan.dev, plan.d_tw, mperm);
+    } else if (threads == 512) {
+        if (int rc = set_lds(ctx, colpass_kernel<OutT, CH, C, 512>, lds)) return rc;
+        hipLaunchKernelGGL((colpass_kernel<OutT, CH, C, 512>), dim3(grid), dim3(512), lds, ctx->stream, planes, dst, rows, cols, pad, plan.dev, plan.d_tw, mperm);
+    } else {
+        if (int rc = set_lds(ctx, colpass_kernel<OutT, CH, C>, lds)) return rc;
+        hipLaunchKernelGGL((colpass_kernel<OutT, CH, C>), dim3(grid), dim3(kThreads), lds, ctx->stream, planes, dst, rows, cols, pad, plan.dev, plan.d_tw, mperm);
+    }
     HIP_TRY(ctx, hipGetLastError());
     return BLUR_OK;
 }
