@@ -169,7 +169,8 @@ class BlurContext:
         return g.value
 
     def timing_enable(self, on=True):
-        self._check(self._lib.blur_ctx_timing_enable(self._h, 1 if on else 0))
+        """per-kernel HIP events on the launch stream: True / 1 = every timed launch, 2 = slot 0 only (the dominant kernel), False = off"""
+        self._check(self._lib.blur_ctx_timing_enable(self._h, 2 if on == 2 and on is not True else (1 if on else 0)))
 
     def timing(self, reset=True):
         ms = (C.c_double * 2)()

@@ -259,11 +259,13 @@ struct BxHorzGeom {
     int ml, mr, mpitch;               // margin bytes left / right of the row, bytes of margins per row (ml + 16 + 16 + mr)
 };
 
+constexpr int kMarginRows = 8;
+
 __global__ __launch_bounds__(256) void bx_margins_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ margins, BxHorzGeom g)
 {
-    // one thread per margin byte of row blockIdx.y; positions are taken relative to the row's end they belong to, so every
-    // division is of a small number by C = 1, 3 or 4 (multiply and shift)
-    const int k = blockIdx.x * 256 + threadIdx.x, row = blockIdx.y;
+    // one thread per margin byte of kMarginRows rows (blockIdx.y); positions are taken relative to the row's end they belong to, so
+    // every division is of a small number by C = 1, 3 or 4 (multiply and shift)
+    const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= g.mpitch) return;
     const int w = g.pitch / g.C;
     const bool left = k < g.ml + 16;
@@ -276,7 +278,13 @@ __global__ __launch_bounds__(256) void bx_margins_kernel(const uint8_t* __restri
         x = x >= w ? 2 * (w - 1) - x : x;
     }
     x = w > 1 ? x : 0;
-    margins[static_cast<size_t>(row) * g.mpitch + k] = in[static_cast<size_t>(row) * g.pitch + x * g.C + c];
+    const int r0 = blockIdx.y * kMarginRows, r1 = min(g.h, r0 + kMarginRows);
+    uint8_t v[kMarginRows];
+#pragma unroll
+    for (int i = 0; i < kMarginRows; ++i) v[i] = in[static_cast<size_t>(min(r0 + i, g.h - 1)) * g.pitch + x * g.C + c];
+#pragma unroll
+    for (int i = 0; i < kMarginRows; ++i)
+        if (r0 + i < r1) margins[static_cast<size_t>(r0 + i) * g.mpitch + k] = v[i];
 }
 
 __device__ __forceinline__ void bx_transpose_groups(uint32_t (&x)[4])
@@ -414,7 +422,7 @@ hipError_t bx_launch_horz(hipStream_t st, const uint8_t* in, uint8_t* out, uint8
     if (nseg < 1) nseg = 1;
     g.seg_bytes = ((g.pitch + nseg - 1) / nseg + 63) / 64 * 64;
     g.nseg = (g.pitch + g.seg_bytes - 1) / g.seg_bytes;
-    hipLaunchKernelGGL(bx_margins_kernel, dim3((g.mpitch + 255) / 256, g.h), dim3(256), 0, st, in, margins, g);
+    hipLaunchKernelGGL(bx_margins_kernel, dim3((g.mpitch + 255) / 256, (g.h + kMarginRows - 1) / kMarginRows), dim3(256), 0, st, in, margins, g);
     const int nwaves = g.ngroups * g.nseg;
     hipLaunchKernelGGL((bx_horz_kernel<NB, P, NT>), dim3((nwaves + 3) / 4), dim3(256), 0, st, in, out, margins, g, s_band, mul, nwaves);
     return hipGetLastError();

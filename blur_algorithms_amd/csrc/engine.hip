@@ -662,7 +662,7 @@ struct blur_ctx {
     int last_family = -1;         // kernels the last u8c3 blur used: 0 run-time plans, 1 specialised rows-first, 2 wave-resident, 3 whole-image 2D, 4 matrix-core (two kernels), 6 fused matrix-core
     void* host_stage = nullptr;   // device staging of the host-pointer entry points (kept between calls: no allocation per frame)
     size_t host_stage_bytes = 0;
-    bool timing = false;
+    int timing = 0;              // 0 off, 1 every timed launch, 2 slot 0 only (blur_ctx_timing_enable)
     std::vector<std::tuple<hipEvent_t, hipEvent_t, int, int>> ev_busy;   // start, stop, kernel (0 row / 1 column), frames
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev_free;
     double ms[2] = { 0, 0 };
@@ -811,7 +811,7 @@ static int timing_drain(blur_ctx* ctx)
 
 struct TimedLaunch {
     blur_ctx* ctx; int which; int nframes; hipEvent_t a = nullptr, b = nullptr; bool on;
-    TimedLaunch(blur_ctx* c, int w, int nf = 1) : ctx(c), which(w), nframes(nf), on(c->timing)
+    TimedLaunch(blur_ctx* c, int w, int nf = 1) : ctx(c), which(w), nframes(nf), on(c->timing == 1 || (c->timing == 2 && w == 0))
     {
         if (!on) return;
         if (ctx->ev_busy.size() >= 8192) timing_drain(ctx);
@@ -1503,7 +1503,7 @@ const char* blur_last_error(const blur_ctx* ctx) { return ctx ? ctx->err.c_str()
 int blur_ctx_timing_enable(blur_ctx* ctx, int on)
 {
     if (!ctx) return BLUR_ERR_INVALID;
-    ctx->timing = on != 0;
+    ctx->timing = on == 2 ? 2 : on != 0 ? 1 : 0;
     return BLUR_OK;
 }
 

@@ -121,7 +121,9 @@ const char* blur_last_error(const blur_ctx* ctx);
    of the row-pass and column-pass kernels is bracketed by events; blur_ctx_timing()
    synchronises, then returns the summed milliseconds, the launch counts and the number of
    frames those launches covered (a batch launch processes several frames) since the last
-   reset:  out_ms[0]=row pass, out_ms[1]=column pass; the others likewise. */
+   reset:  out_ms[0]=row pass, out_ms[1]=column pass; the others likewise.  (The fused engine: [0] = the fused kernel,
+   [1] = its side kernels per call.)  on = 2 brackets slot 0 only: an event between two kernels keeps the second from
+   starting while the first drains, about 3.5 us each on MI355X, and a measurement run may want to pay that once per call. */
 int blur_ctx_timing_enable(blur_ctx* ctx, int on);
 int blur_ctx_timing(blur_ctx* ctx, double out_ms[2], int out_launches[2], int out_frames[2], int reset);
 
