@@ -207,14 +207,19 @@ def box_config(args, torch, B):
     for _ in range(max(args.warmup, 3)):
         ctx.fastboxblur(img, k, passes)
     torch.cuda.synchronize(dev)
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    # the contract's timed region without events (an event between two launches delays the second by about 3.5 us: 3 % here), then
+    # the same K steps again with one event per step for the percentiles
     t0 = time.perf_counter()
+    for i in range(args.steps):
+        ctx.fastboxblur(img, k, passes)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     marks[0].record()
     for i in range(args.steps):
         ctx.fastboxblur(img, k, passes)
         marks[i + 1].record()
     torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
     per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     px = rows * cols
     alg = 12 * passes * px
@@ -224,7 +229,7 @@ def box_config(args, torch, B):
            "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8 (i8 matrix-core sums in i32, 24-bit multiply-high rounding per sweep)", "data": "synthetic",
            "config": {"workload": c["label"] + ", in place, device-resident", "frames_per_gpu": 1},
-           "ms_per_step_gpu": percentiles(per_step),
+           "ms_per_step_gpu": percentiles(per_step),      # of a second pass of the same K steps with one event per step
            # BASELINE.md section 3 prices a P-pass box blur at 12 P B/px (every sweep reads and writes the image); `frac` is against that
            # figure.  The kernels as built move the image twice (all horizontal sweeps in one launch, all vertical ones in another):
            # 12 B/px, reported as `moved`.
@@ -450,19 +455,16 @@ def main():
             for _ in range(4):
                 ctx.pffft_(frames, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch, wave_resident=wr, engine=eng)
             torch.cuda.synchronize(dev)
-    # The fused engine is one big kernel and three small ones per step, and an event between two kernels keeps the second from
-    # starting while the first drains (measured per step on one box: 0.353 ms without events, 0.361 with the fused kernel's pair,
-    # 0.367 with every kernel's and one per step).  So the contract's timed region carries no events there, and a second pass of the
-    # same K steps right after it carries all of them: kernel durations for `roofline` (they agree with rocprofv3's kernel trace;
-    # an interval that starts right behind another kernel would also count the hand-over bubble) and the per-step percentiles
-    # (`instrumented_pass`).  Engines with two kernels of similar length keep their events in the one timed region as before.
-    ctx.pffft_(frames, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch, wave_resident=wr, engine=eng)
-    two_regions = ctx.last_family() == 6 and not args.no_events
-    elapsed, tm, per_step = timed_run(frames, args.steps, args.warmup, 0 if (two_regions or args.no_events) else 1,
-                                      step_events=not two_regions and not args.no_step_events)
+    # An event between two kernels keeps the second from starting while the first drains (the fused engine's step is one big kernel
+    # and three small ones; measured per step on one box: 0.353 ms without events, 0.361 with the fused kernel's pair, 0.367 with
+    # every kernel's and one per step).  So the contract's timed region carries no events, and a second pass of the same K steps
+    # right after it carries all of them: kernel durations for `roofline` (they agree with rocprofv3's kernel trace) and the
+    # per-step percentiles (`instrumented_pass`).
+    two_regions = not args.no_events
+    elapsed, tm, per_step = timed_run(frames, args.steps, args.warmup, 0, step_events=not two_regions and not args.no_step_events)
     instrumented_ms = None
     if two_regions:
-        inst_elapsed, tm, per_step = timed_run(frames, args.steps, 0, 1, step_events=True)
+        inst_elapsed, tm, per_step = timed_run(frames, args.steps, 0, 1, step_events=not args.no_step_events)
         instrumented_ms = 1e3 * inst_elapsed / args.steps
     natural = None
     if args.data == "synthetic" and not args.no_natural:
