@@ -115,10 +115,11 @@ DTYPE = {4: "f16 hi+lo operands (u8 pixels exact, taps split in two binary16 hal
 
 def fused_launch_shape(rows, cols, pad, frames, num_cus=256):
     """what fx_launch_u8 (csrc/fx_kernels.hpp) launches for this call: window blocks, tasks, and the matrix instructions it executes"""
-    nkb = next(n for n in (3, 5, 7, 9, 11) if 8 * (n - 2) >= pad)
+    nkb = next(n for n in (3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23) if 8 * (n - 2) >= pad)
     nt = (nkb - 1) // 2
     chunks, ntiles = -(-cols // 128), -(-rows // 32)
-    stripes = chunks * frames
+    wide = nkb > 11                                   # fw_kernels.hpp: one channel per workgroup, so three times the tasks
+    stripes = chunks * frames * (3 if wide else 1)
     best = None
     for n in range(1, -(-ntiles // nt) + 1):
         t = -(-(-(-ntiles // n)) // nt) * nt
@@ -128,7 +129,7 @@ def fused_launch_shape(rows, cols, pad, frames, num_cus=256):
             best = (span, ns, t)
     _, nseg, tps = best
     steps = sum(min(tps, ntiles - sg * tps) + nt for sg in range(nseg))          # per strip of columns
-    mfma_per_wave_step = 3 * 5 * nkb                                             # 3 channels x (2 row + 3 column products) x window blocks
+    mfma_per_wave_step = (1 if wide else 3) * 5 * nkb                            # channels x (2 row + 3 column products) x window blocks
     mfmas = stripes * 4 * (steps * mfma_per_wave_step + nseg * 2 * nkb)          # 4 waves per task; the prologue's first row pass
     return {"nkb": nkb, "tasks": stripes * nseg, "segments_per_strip": nseg, "steps_per_strip": steps, "mfma_instructions": mfmas,
             "flops": mfmas * 2 * 32 * 32 * 16}
@@ -546,7 +547,7 @@ def main():
             k_ms = tm["row_ms"] / tm["row_launches"]
             fpl = tm["row_frames"] / tm["row_launches"]
             shape = fused_launch_shape(rows, cols, sz["pad"], int(round(fpl)))
-            name = "fx_blur_u8<%d, %s>" % (shape["nkb"], "true")
+            name = ("fw_blur_u8<%d, %s>" if shape["nkb"] > 11 else "fx_blur_u8<%d, %s>") % (shape["nkb"], "true")
             achieved = shape["flops"] / (k_ms * 1e-3) / 1e12
             name2, traffic = pmc_traffic("blur", fpl, family)
             side_ms = tm["col_ms"] / max(args.steps, 1)                # per step: the quirk's pre-pass (with the edge strips) and term kernels

@@ -1088,6 +1088,13 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
 }
 
 // ptrs_aligned: the frame pointers of the call are 4-byte aligned (a condition of the fused kernel)
+// BLUR_FUSED_WIDE=1 (developer switch): the library's own choice includes the wide fused kernels
+static bool fused_wide_auto()
+{
+    static const bool on = [] { const char* e = getenv("BLUR_FUSED_WIDE"); return e && *e && *e != '0'; }();
+    return on;
+}
+
 static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p, bool u8c3 = true,
                    const CustomKernel* ck = nullptr, bool allow_wr = true, bool ptrs_aligned = false)
 {
@@ -1112,6 +1119,8 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     //   | engine                      | where                                                   | measured (MI355X, 8 frames per call)            |
     //   | fused matrix-core kernel    | pad <= 72 (sigma <~ 22), cols % 4 == 0, aligned frames,  | 4K sigma 20: 47 us per frame against 70 for the  |
     //   |                             | non-negative taps with sum <= 1                         | two kernels and 105 for the FFT kernels          |
+    //   | fused kernel, wide windows  | pad 73 .. 168 on frames >= 6 MP (not where the next row | 4K sigma 30: 98 GP/s against 85 / 70; 8K sigma 40 |
+    //   |                             | applies), same conditions                               | single frame 79 against 54 / 26                   |
     //   | FFT, compile-time families  | frames < 1 MP, or pad > 136 on frames >= 6 MP           | 1080p sigma 20 single frame 72 / 78 us;          |
     //   |                             |                                                         | 4K sigma 50: 72 GP/s against 63                  |
     //   | two-kernel matrix engine    | pad <= 168, non-negative taps with sum <= 1             | 4K sigma 26 / 30 / 36: 103 / 87 / 80 GP/s (FFT 76)|
@@ -1149,6 +1158,14 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     }
     if (allow_fast && allow_wr && (choice == BLUR_ENGINE_FUSED || choice == BLUR_ENGINE_AUTO)) {
         const FxEntry* fe = find_fx_entry(p.sz.pad);
+        // the one-channel-per-workgroup kernels for wide windows (fw_kernels.hpp; measured against the two-kernel engine / the FFT
+        // kernels, GP/s: 4K sigma 30 single frame 61 / 50 / 57, eight frames 98 / 85 / 70; 8K sigma 40 single 79 / 54 / 26;
+        // 1080p sigma 30 single 29 / 31 / 36, eight 68 / 63 / 59; 1000 x 1500 sigma 38.7 single 17 / 21 / 13; 4K sigma 50 single
+        // 39 / 37 / 57, eight 68-73 / 63 / 63-74, sigma 44 eight 76 / 63 / 64): the library's own choice for frames of 6 MP and more,
+        // except the widest window (23 blocks, pad > 152) where the FFT engine has a compile-time family for the frame (small_fft
+        // above).  BLUR_FUSED_WIDE=1: always.
+        if (fe && fe->nkb > 11 && choice == BLUR_ENGINE_AUTO && !fused_wide_auto() &&
+            (static_cast<long long>(rows) * cols < 6000000ll || (small_fft && fe->nkb >= 23))) fe = nullptr;
         const char* why = nullptr;
         if (!fe) why = "fused matrix-core engine: no kernel instantiated for this pad";
         else if (static_cast<long long>(rows) * cols * 3 >= (1ll << 32)) why = "fused matrix-core engine: frame too large for 32-bit offsets";
@@ -1594,7 +1611,7 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     if (!g.aligned) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: frame pointers must be 4-byte aligned");
     const int qrows = 32 * (g.ntiles + nt), qpitch = (3 * cols + 31) & ~31;
     {   // the edge chunks' windows
-        const int win = kFxChunk + 2 * pada, nstrips = 1 + g.nright;
+        const int win = kFxChunk + 2 * pada, nstrips = fx_left_strips(pada) + g.nright;
         const size_t bytes = static_cast<size_t>(nframes) * nstrips * rows * win * 3 + 64;
         if (ctx->fx_strips_bytes < bytes) {
             if (ctx->fx_strips) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->fx_strips)); ctx->fx_strips = nullptr; ctx->fx_strips_bytes = 0; }
@@ -1606,7 +1623,7 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     const int strip_blocks = (((rows + 3) / 4) * ((kFxChunk + 2 * pada) / 4) + 255) / 256, chunks_x = (cols + kFxChunk - 1) / kFxChunk;
     if (!p.mx_quirk) {
         TimedLaunch t(ctx, 1, nframes);
-        hipLaunchKernelGGL(fx_prepass, dim3(strip_blocks * (1 + g.nright) * nframes), dim3(256), 0, ctx->stream, d_src, nullptr, nullptr, nullptr, ctx->fx_strips, rows, cols,
+        hipLaunchKernelGGL(fx_prepass, dim3(strip_blocks * (fx_left_strips(pada) + g.nright) * nframes), dim3(256), 0, ctx->stream, d_src, nullptr, nullptr, nullptr, ctx->fx_strips, rows, cols,
                            p.sz.pad, pada, 1, 1, 0, chunks_x, g.nright, strip_blocks);
         HIP_TRY(ctx, hipGetLastError());
     }
@@ -1638,7 +1655,7 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         qcol = qrow + static_cast<size_t>(3) * qrows * nframes;
         { TimedLaunch t(ctx, 1, nframes);
           const int n_alt = nbands * nbatches * nframes;
-          hipLaunchKernelGGL(fx_prepass, dim3(n_alt + strip_blocks * (1 + g.nright) * nframes), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, ctx->fx_strips, rows, cols,
+          hipLaunchKernelGGL(fx_prepass, dim3(n_alt + strip_blocks * (fx_left_strips(pada) + g.nright) * nframes), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, ctx->fx_strips, rows, cols,
                              p.sz.pad, pada, nbands, nbatches, n_alt, chunks_x, g.nright, strip_blocks);
           HIP_TRY(ctx, hipGetLastError());
           const int nrb = (qrows + 255) / 256, nvb = (3 * cols + 255) / 256, ncb = (qpitch + 255) / 256;

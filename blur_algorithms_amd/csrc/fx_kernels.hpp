@@ -52,6 +52,8 @@ struct FxGeom {
 };
 
 constexpr int kFxChunk = 128;     // pixel columns per workgroup
+// chunks at the left edge whose window (from 128 xc - pada) starts left of the image: they read a strip
+__host__ __device__ constexpr int fx_left_strips(int pada) { return pada > 0 ? (pada + kFxChunk - 1) / kFxChunk : 1; }
 
 template <int NKB> struct FxCfg {
     static constexpr int PADA = 8 * (NKB - 2), WIN = kFxChunk + 2 * PADA, GPR = WIN / 4, PER = (GPR + 7) / 8;
@@ -173,12 +175,13 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     // staging in three chunks of three 12-byte groups: commit chunk j of window s, then refill the registers with window s + 1
     // Reflect-101 along the rows (Source.cpp:525-529) never shows in this kernel: a chunk whose window reaches over the image's left
     // or right edge reads it from a STRIP -- a copy of its 128 + 2 PADA window columns with the mirrored pixels in place, written by
-    // fx_edge_strips before the launch (1 + nright strips per frame) -- and every other chunk's window lies inside the image.  So a
+    // fx_edge_strips before the launch (left + nright strips per frame) -- and every other chunk's window lies inside the image.  So a
     // window row is 17 x 4 twelve-byte groups at base + row * pitch for every workgroup; the source is a buffer resource (groups
     // past the end of the last row read as zero; they only meet zero taps).
-    const int sidx = xc == 0 ? 0 : (xc >= chunks - g.nright ? 1 + xc - (chunks - g.nright) : -1);      // uniform
+    constexpr int NLEFT = fx_left_strips(PADA);
+    const int sidx = xc < NLEFT ? xc : (xc >= chunks - g.nright ? NLEFT + xc - (chunks - g.nright) : -1);      // uniform
     const uint32_t pitch = sidx >= 0 ? 3u * C::WIN : 3u * static_cast<uint32_t>(g.cols);
-    const uint8_t* wbase = sidx >= 0 ? strips + (static_cast<size_t>(f) * (1 + g.nright) + sidx) * g.rows * (3 * C::WIN) : img + 3 * (x0 - PADA);
+    const uint8_t* wbase = sidx >= 0 ? strips + (static_cast<size_t>(f) * (NLEFT + g.nright) + sidx) * g.rows * (3 * C::WIN) : img + 3 * (x0 - PADA);
     const uint32_t wbytes = sidx >= 0 ? static_cast<uint32_t>(g.rows) * 3u * C::WIN : (static_cast<uint32_t>(g.rows) * g.cols - static_cast<uint32_t>(x0 - PADA)) * 3u;
     const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wbase), 0, wbytes, kMxRsrcWord3);
     auto issue_chunk = [&](int s, int j) __attribute__((always_inline)) {
@@ -550,7 +553,7 @@ inline int fx_right_strips(int cols, int pada)
 {
     const int chunks = (cols + kFxChunk - 1) / kFxChunk;
     int n = 0;
-    for (int xc = chunks - 1; xc >= 1 && kFxChunk * xc + kFxChunk + pada > cols; --xc) ++n;
+    for (int xc = chunks - 1; xc >= fx_left_strips(pada) && kFxChunk * xc + kFxChunk + pada > cols; --xc) ++n;
     return n;
 }
 
@@ -563,7 +566,8 @@ __device__ __forceinline__ void fx_edge_strips_body(const uint8_t* __restrict__ 
                                                     int bx, int sidx, int f)
 {
     const int win = kFxChunk + 2 * pada, gpr = win / 4;
-    const int xc = sidx == 0 ? 0 : chunks - nright + sidx - 1, x0 = kFxChunk * xc;
+    const int nleft = fx_left_strips(pada);
+    const int xc = sidx < nleft ? sidx : chunks - nright + sidx - nleft, x0 = kFxChunk * xc;
     const int i = bx * 256 + threadIdx.x, rq = (rows + 3) / 4;
     if (i >= rq * gpr) return;
     const int r4 = i / gpr, gidx = i - r4 * gpr;
@@ -573,7 +577,7 @@ __device__ __forceinline__ void fx_edge_strips_body(const uint8_t* __restrict__ 
     const bool fast = xs >= 0 && xs + 3 < cols;
     typedef uint32_t u3 __attribute__((ext_vector_type(3)));
     const uint8_t* img = src + static_cast<size_t>(f) * rows * cols * 3;
-    uint8_t* sbase = strips + (static_cast<size_t>(f) * (1 + nright) + sidx) * rows * (3 * win) + 12 * gidx;
+    uint8_t* sbase = strips + (static_cast<size_t>(f) * (nleft + nright) + sidx) * rows * (3 * win) + 12 * gidx;
     u3 d[4];
     if (fast) {
 #pragma unroll
@@ -739,7 +743,7 @@ __global__ __launch_bounds__(256) void fx_prepass(const uint8_t* __restrict__ sr
         fx_altsums_body(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred);
     } else {
         b -= n_alt;
-        const int nstrips = 1 + nright, bx = b % strip_blocks, sidx = (b / strip_blocks) % nstrips, f = b / (strip_blocks * nstrips);
+        const int nstrips = fx_left_strips(pada) + nright, bx = b % strip_blocks, sidx = (b / strip_blocks) % nstrips, f = b / (strip_blocks * nstrips);
         fx_edge_strips_body(src, strips, rows, cols, pada, chunks, nright, bx, sidx, f);
     }
 }

@@ -60,6 +60,65 @@ def test_fused_engine_row_pass_float_planes(ctx, rows, cols, sigma, quirk):
         assert err <= FLOAT_TOL, "channel %d: max |err| %.3g" % (c, err)
 
 
+# the wide fused kernels (fw_kernels.hpp: one channel per workgroup, 13 .. 23 window blocks, pad 73 .. 168): one sigma per window size
+# on shapes with one chunk, several chunks with both kinds of edge strips (two chunks reach over the left edge once pad > 128), ragged
+# heights, narrow images
+WIDE = [(300, 400, 25.0, 13), (200, 332, 30.0, 15), (340, 132, 36.0, 17), (300, 644, 40.0, 19), (320, 520, 44.0, 21), (400, 520, 50.0, 23), (350, 256, 50.0, 23),
+        (180, 644, 44.0, 21), (541, 1028, 33.0, 17), (170, 172, 50.0, 13)]
+
+
+@pytest.mark.parametrize("rows,cols,sigma,nkb", WIDE)
+@pytest.mark.parametrize("quirk", [False, True])
+def test_wide_fused_kernels_match_the_oracle(ctx, rows, cols, sigma, nkb, quirk):
+    import blur_algorithms_amd as B
+    from oracle import oracle as O
+    torch = _torch()
+    pad = B.pffft_sizing(rows, cols, sigma)["pad"]
+    assert 8 * (nkb - 4) < pad <= 8 * (nkb - 2)
+    img = _rand_img(rows, cols, rows + 3 * cols)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=quirk, want_planes=True)
+    got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, nyquist_quirk=quirk, engine="fused").cpu().numpy()
+    assert _fam(ctx) == 6
+    assert_u8_parity(got, want, planes)
+
+
+def test_wide_fused_batch_segments_in_place_and_extremes(ctx):
+    """a batch equals its frames blurred alone (segments differ: one tall frame is cut, a batch is not), in place equals out of place,
+    a constant image stays constant, and the 0 / 255 images that stretch the quirk's terms agree with the oracle"""
+    from oracle import oracle as O
+    torch = _torch()
+    frames = torch.from_numpy(np.random.default_rng(19).integers(0, 256, (3, 700, 392, 3), dtype=np.uint8)).cuda()
+    one = torch.stack([ctx.pffft_(f.clone(), 40.0, engine="fused") for f in frames])
+    assert torch.equal(ctx.pffft_(frames.clone(), 40.0, engine="fused"), one)
+    inplace = frames.clone()
+    ctx.pffft_(inplace, 40.0, out=inplace, engine="fused")
+    assert torch.equal(inplace, one)
+    const = torch.full((300, 300, 3), 93, dtype=torch.uint8, device="cuda")
+    assert int((ctx.pffft_(const.clone(), 45.0, engine="fused") != 93).sum()) == 0
+    rows, cols, sigma = 300, 388, 40.0
+    x = np.arange(cols)[None, :, None]
+    y = np.arange(rows)[:, None, None]
+    for name, img in (("columns", np.broadcast_to(255 * (x & 1), (rows, cols, 3))), ("rows", np.broadcast_to(255 * (y & 1), (rows, cols, 3))),
+                      ("checker", np.broadcast_to(255 * ((x + y) & 1), (rows, cols, 3))), ("white", np.full((rows, cols, 3), 255))):
+        img = np.ascontiguousarray(img).astype(np.uint8)
+        want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=True, want_planes=True)
+        got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, engine="fused").cpu().numpy()
+        assert_u8_parity(got, want, planes), name
+
+
+def test_wide_fused_4k_frame_against_the_two_kernel_engine(ctx):
+    """a whole 4K frame, sigma 36 (the library's own choice there): at most one grey level from the two-kernel engine's bytes, on fewer
+    than 1e-4 of them (both are held to the oracle on smaller shapes; the float64 oracle takes minutes at this size)"""
+    torch = _torch()
+    g = torch.Generator(device="cuda").manual_seed(8)
+    fr = torch.randint(0, 256, (2, 2160, 3840, 3), dtype=torch.uint8, device="cuda", generator=g)
+    a = ctx.pffft_(fr, 36.0, out=torch.empty_like(fr))
+    assert _fam(ctx) == 6
+    b = ctx.pffft_(fr, 36.0, out=torch.empty_like(fr), engine="matrix")
+    d = (a.int() - b.int()).abs()
+    assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 1e-4
+
+
 # one sigma per instantiated window size (NKB = 3, 5, 7, 9, 11: pad <= 8, 24, 40, 56, 72); sigma 2.0 is the truncated Gaussian
 # whose alternating sum is most negative (Nyquist gain 1.0037)
 EVERY_WINDOW = [(2.0, 3), (2.5, 3), (7.5, 5), (12.5, 7), (17.0, 9), (22.0, 11)]
@@ -115,7 +174,7 @@ def test_fused_engine_extreme_images(ctx):
 
 
 def test_where_the_fused_kernel_does_not_apply(ctx):
-    """an image width that is no multiple of 4, an unaligned frame pointer, a kernel wider than 145 taps: asking for the fused
+    """an image width that is no multiple of 4, an unaligned frame pointer, a kernel wider than 337 taps: asking for the fused
     kernel is an error, the library's own choice takes another engine and gives the oracle's bytes"""
     from blur_algorithms_amd.api import BlurError
     from oracle import oracle as O
@@ -129,7 +188,7 @@ def test_where_the_fused_kernel_does_not_apply(ctx):
     assert_u8_parity(got, want, planes)
     img4 = _rand_img(210, 332, 6)
     with pytest.raises(BlurError):
-        ctx.pffft_(torch.from_numpy(img4).cuda(), 30.0, engine="fused")          # pad 98 > 72
+        ctx.pffft_(torch.from_numpy(_rand_img(400, 400, 7)).cuda(), 55.0, engine="fused")          # pad 182 > 168
     buf = torch.zeros(img4.size + 16, dtype=torch.uint8, device="cuda")
     off = buf[2:2 + img4.size].view(210, 332, 3)
     off.copy_(torch.from_numpy(img4))

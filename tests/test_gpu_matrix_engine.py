@@ -66,9 +66,9 @@ def test_every_instantiated_window(ctx, sigma, nkb):
 
 def test_the_librarys_choice_of_engine(ctx):
     """BLUR_ENGINE_AUTO (include/blur_amd.h): the fused matrix-core kernel (family 6) where the kernel's half width is at most 72,
-    the width a multiple of 4 and the frames aligned; else the two-kernel matrix engine (family 4) for frames of 1 MP and more whose
-    kernel it can hold; the FFT kernels for pad > 168, for kernels with negative taps and for small frames or very wide kernels
-    where the FFT engine has a compile-time family.  The choice never depends on the number of frames.  Asking for an engine
+    the width a multiple of 4 and the frames aligned, and its wide-window form (half widths 73 .. 168) on frames of 6 MP and more;
+    else the two-kernel matrix engine (family 4) for frames of 1 MP and more whose kernel it can hold; the FFT kernels for pad > 168,
+    for kernels with negative taps and for small frames or the widest windows where the FFT engine has a compile-time family.  The choice never depends on the number of frames.  Asking for an engine
     explicitly where it cannot run is an error."""
     from blur_algorithms_amd.api import BlurError
     torch = _torch()
@@ -85,21 +85,27 @@ def test_the_librarys_choice_of_engine(ctx):
     assert fam() == 6
     ctx.pffft_(odd, 20.0)                                         # width 1921: the two-kernel engine
     assert fam() == 4
-    ctx.pffft_(batch, 30.0)                                       # pad 98: beyond the fused kernel's windows
+    ctx.pffft_(batch, 30.0)                                       # pad 98 on a 2 MP frame: the two kernels (the wide fused kernels from 6 MP)
     assert fam() == 4
     ctx.pffft_(batch, 60.0)                                       # pad 195: beyond every matrix-core window
     assert fam() not in (4, 6)
     with pytest.raises(BlurError):
         ctx.pffft_(batch, 60.0, engine="matrix")
+    ctx.pffft_(batch, 30.0, engine="fused")                       # asked for: the wide fused kernel
+    assert fam() == 6
     with pytest.raises(BlurError):
-        ctx.pffft_(batch, 30.0, engine="fused")
+        ctx.pffft_(batch, 60.0, engine="fused")
     small_odd = torch.from_numpy(_rand_img(400, 421, 1)).cuda()
     ctx.pffft_(small_odd, 20.0)                                   # 0.17 MP, wave-resident FFT kernels exist for 530 x 551 points
     assert fam() == 2
     uhd = torch.zeros((2, 2160, 3840, 3), dtype=torch.uint8, device="cuda")
     ctx.pffft_(uhd, 20.0)
     assert fam() == 6
-    ctx.pffft_(uhd, 50.0)                                         # 4K, 327 taps: the specialised FFT kernels (4320 / 2560) are faster
+    ctx.pffft_(uhd, 30.0)                                         # 4K, pad 98: the wide fused kernel
+    assert fam() == 6
+    ctx.pffft_(uhd, 44.0)                                         # pad 145, 21 window blocks: still
+    assert fam() == 6
+    ctx.pffft_(uhd, 50.0)                                         # 4K, 327 taps (23 blocks): the specialised FFT kernels (4320 / 2560)
     assert fam() == 1
     ctx.pffft_(uhd, 50.0, engine="matrix")
     assert fam() == 4
