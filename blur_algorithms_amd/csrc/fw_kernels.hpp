@@ -67,10 +67,6 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
     const mx_half8* tlp = reinterpret_cast<const mx_half8*>(fw_lds + C::TLOFF) + lane;
     auto tlo = [&](int kb) __attribute__((always_inline)) { return kb < TLR ? tlr[kb < TLR ? kb : 0] : tlp[kb * 64]; };
 
-    const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
-    const int Q = m >> 2, q = m & 3;
-    const int xpix = x0 + 32 * wave + 4 * Q;                       // first of the lane's 4 pixels after the transposes
-    const bool in_cols = xpix < g.cols;
     float cpos, cneg;
     {
         const int x = x0 + 32 * wave + m;
@@ -87,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
     for (int k = 0; k < NT; ++k) acc[k] = zero;
     mx_float16 arow = zero, tfin = zero;
     uint32_t hl[2][2][8];               // hand-off, two of them (the next step's is made while this step's is consumed): [hi, lo][packed row pairs], block b = entries 4 b .. 4 b + 3
-    uint32_t rr[4];                     // finished tile per row group: the channel's bytes of 4 pixels of one row
+    uint32_t rr[4];                     // finished tile per row group: the channel's bytes of 4 rows of the lane's pixel column
 
     const int s0 = tile0, s1 = tile1 + NT;
     // the window's source: the image, or (edge chunks) a strip with the mirrored pixels in place -- as in fx_kernels.hpp
@@ -100,7 +96,8 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
     const int srow = tid >> 3, g0 = tid & 7;
     uint32_t raw[PER][3];
     float qraw = 0.f;
-    // the window of step s: PER twelve-byte groups per thread, all requested at once (consumed one matrix-heavy pass later)
+    // the window of step s: thread t moves the twelve-byte groups (t & 7) + 8 k of row t >> 3, all requested at once (consumed one
+    // matrix-heavy pass later).  (A mapping with 2 rows x 384 contiguous bytes per wave load instead of 8 x 96 changed nothing.)
     auto issue_window = [&](int s) __attribute__((always_inline)) {
 #ifdef FW_ABL_NOLOAD
         if (s > s0 + 1) return;
@@ -202,7 +199,9 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
             fx_swap4(hp[4 * hf], hp[4 * hf + 2], hp[4 * hf + 1], hp[4 * hf + 3], lp[4 * hf], lp[4 * hf + 2], lp[4 * hf + 1], lp[4 * hf + 3]);
         }
     };
-    // E: one row group (4 rows) of the finished tile -> bytes, 4 x 4 transposed inside the lane quads -> rr[gq]
+    // E: four registers of the finished tile (rows 8 gq + 4 h + 0 .. 3 of the lane's pixel column) -> bytes, kept in rr[gq].  No
+    // transposes: the lane keeps its COLUMN, so a store instruction covers 2 rows x 32 pixels (96-byte spans, two or three cache
+    // lines) instead of 8 rows x 8 quads.
     auto emit_piece = [&](int gq) __attribute__((always_inline)) {
         float fv[4];
 #pragma unroll
@@ -213,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
         // (uint8_t)(v + 0.5f) of the reference (Utils.hpp:189,204-206): truncate, keep the low byte
         const uint32_t b0 = static_cast<uint32_t>(static_cast<int>(fv[0])) & 0xffu, b1 = static_cast<uint32_t>(static_cast<int>(fv[1])) & 0xffu;
         const uint32_t b2 = static_cast<uint32_t>(static_cast<int>(fv[2])) & 0xffu, b3 = static_cast<uint32_t>(static_cast<int>(fv[3]));
-        rr[gq] = fx_quad_transpose(b0 | (b1 << 8) | (b2 << 16) | (b3 << 24), sel1, sel2);
+        rr[gq] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
     };
     // C: column pass of step slot qs from hl (fx_kernels.hpp: colpass): first the tile that FINISHES, last the tile that STARTS
     auto colpass = [&](int qs, int hb, auto beside) __attribute__((always_inline)) {
@@ -247,23 +246,25 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
 #endif
         }
     };
-    // F: the channel's bytes of the finished tile: byte c of every pixel (stride 3).  Buffer stores: rows past the image, lanes right
-    // of it and tiles that do not exist get an offset outside the resource.
+    // F: the channel's bytes of the finished tile: byte c of every pixel (stride 3), rows 8 gq + 4 h + k of the lane's column.  Buffer
+    // stores: rows past the image, lanes right of it and tiles that do not exist get an offset outside the resource.
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out, 0, static_cast<uint32_t>(g.rows) * g.cols * 3u, kMxRsrcWord3);
-    const uint32_t lane_out = (static_cast<uint32_t>(4 * h + q) * g.cols + static_cast<uint32_t>(xpix)) * 3u + static_cast<uint32_t>(c);
+    const int xcol = x0 + 32 * wave + m;
+    const uint32_t lane_out = (static_cast<uint32_t>(4 * h) * g.cols + static_cast<uint32_t>(xcol)) * 3u + static_cast<uint32_t>(c);
+    const uint32_t rowstep = static_cast<uint32_t>(g.cols) * 3u;
     auto store_group = [&](int tile, bool valid, int gq) __attribute__((always_inline)) {
-        const uint32_t rowoff = static_cast<uint32_t>(32 * tile + 8 * gq) * g.cols * 3u;        // uniform
-#ifdef FW_ABL_NOSTORE
-        const bool ok = false && valid;
-#else
-        const bool ok = valid && in_cols && 32 * tile + 8 * gq + 4 * h + q < g.rows;
-#endif
-        const uint32_t off = ok ? lane_out + rowoff : 0xfffffff0u;
+        const int row0 = 32 * tile + 8 * gq + 4 * h;
+        const uint32_t base = lane_out + static_cast<uint32_t>(32 * tile + 8 * gq) * rowstep;
         const uint32_t v = rr[gq];
-        __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(v), rout, off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(v >> 8), rout, ok ? off + 3 : off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(v >> 16), rout, ok ? off + 6 : off, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(v >> 24), rout, ok ? off + 9 : off, 0, 0);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#ifdef FW_ABL_NOSTORE
+            const bool ok = false && valid;
+#else
+            const bool ok = valid && xcol < g.cols && row0 + k < g.rows;
+#endif
+            __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(v >> (8 * k)), rout, ok ? base + k * rowstep : 0xfffffff0u, 0, 0);
+        }
     };
 
     // prologue: windows s0 and s0 + 1 in LDS, the first row pass and its hand-off done
