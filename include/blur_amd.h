@@ -41,15 +41,17 @@ typedef struct blur_ctx blur_ctx;
 /* blur_opts.engine.  Every engine computes the same blur under the same parity contract (Parity); the choice is
    about speed and about what each engine can hold.  engine.hip: prepare() holds the policy table of BLUR_ENGINE_AUTO. */
 enum blur_engine {
-    BLUR_ENGINE_AUTO = 0,            /* fused matrix-core kernel where it exists for the kernel's half width (pad <= 72), the image
-                                        width is a multiple of 4 and the frame pointers are 4-byte aligned; else the two-kernel
-                                        matrix-core engine (pad <= 168, non-negative taps) except where the FFT engine has a
-                                        faster compile-time family (small frames, very wide kernels on 4K frames); else FFT */
+    BLUR_ENGINE_AUTO = 0,            /* fused matrix-core kernel where it exists for the kernel's half width (pad <= 72; pad <= 168
+                                        on frames of 6 MP and more), the image width is a multiple of 4 and the frame pointers
+                                        are 4-byte aligned; else the two-kernel matrix-core engine (pad <= 168, non-negative
+                                        taps) except where the FFT engine has a faster compile-time family (small frames, the
+                                        widest kernels on 4K frames); else FFT */
     BLUR_ENGINE_FFT_ROWS_FIRST = 1,  /* FFT kernels, never the wave-resident family */
     BLUR_ENGINE_FFT_WAVE_RESIDENT = 2, /* FFT kernels, wave-resident (transform length 256 R0, columns first) wherever the image fits */
     BLUR_ENGINE_MATRIX = 3,          /* two-kernel matrix-core engine (mx_kernels.hpp); BLUR_ERR_UNSUPPORTED if it cannot hold the kernel */
     BLUR_ENGINE_FFT = 5,             /* FFT kernels with their own measured choice of family */
-    BLUR_ENGINE_FUSED = 6            /* fused matrix-core kernel (fx_kernels.hpp); BLUR_ERR_UNSUPPORTED where it does not apply */
+    BLUR_ENGINE_FUSED = 6            /* fused matrix-core kernels (fx_kernels.hpp, pad <= 72; fw_kernels.hpp, pad <= 168); BLUR_ERR_UNSUPPORTED
+                                        where they do not apply */
 };
 
 /* Options of the whole-image blur.  Zero-initialise, then blur_opts_default(). */
