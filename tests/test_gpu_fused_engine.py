@@ -212,18 +212,15 @@ def test_fused_engine_metric_frame(ctx):
     assert n < 2000
 
 
-def test_fused_engine_fuzz_time_boxed(ctx):
-    """random shapes (widths below one chunk of 128 columns, heights below one tile of 32 rows, ragged last chunks and tiles), random
-    sigma over every window size, both quirk settings, uniform and 0 / 255 images, in place and out of place, single frames and
-    small batches, against the float64 oracle; with redzones around the image buffers.  About 30 s."""
+def _fused_fuzz(ctx, sigmas, seed, seconds):
     import time
     from oracle import oracle as O
     torch = _torch()
-    rng = np.random.default_rng(20261005)
-    t_end = time.time() + 30.0
+    rng = np.random.default_rng(seed)
+    t_end = time.time() + seconds
     cases = 0
     while time.time() < t_end or cases < 15:
-        sigma = float(rng.choice([0.7, 1.5, 3.0, 6.0, 9.5, 14.0, 17.5, 20.0, 22.0]))
+        sigma = float(rng.choice(sigmas))
         pad = O.pffft_sizing(4096, 4096, sigma)["pad"]
         rows = int(rng.integers(pad + 1, pad + 300))
         cols = (int(rng.integers(pad + 1, pad + 460)) + 3) & ~3
@@ -252,3 +249,16 @@ def test_fused_engine_fuzz_time_boxed(ctx):
         except AssertionError as e:
             raise AssertionError("rows=%d cols=%d sigma=%r quirk=%d kind=%s inplace=%d frames=%d: %s" % (rows, cols, sigma, quirk, kind, inplace, nf, e))
         cases += 1
+
+
+def test_fused_engine_fuzz_time_boxed(ctx):
+    """random shapes (widths below one chunk of 128 columns, heights below one tile of 32 rows, ragged last chunks and tiles), random
+    sigma over every window size, both quirk settings, uniform and 0 / 255 images, in place and out of place, single frames and
+    small batches, against the float64 oracle; with redzones around the image buffers.  About 30 s."""
+    _fused_fuzz(ctx, [0.7, 1.5, 3.0, 6.0, 9.5, 14.0, 17.5, 20.0, 22.0], 20261005, 30.0)
+
+
+def test_wide_fused_kernels_fuzz_time_boxed(ctx):
+    """the same for the wide kernels (sigma 23 .. 50: 13 .. 23 window blocks; one or two chunks reading mirrored pixels at the left
+    edge, images narrower than the window).  About 30 s."""
+    _fused_fuzz(ctx, [23.0, 25.5, 28.0, 31.0, 34.0, 37.5, 41.0, 44.5, 48.0, 50.0], 20261006, 30.0)
