@@ -549,7 +549,7 @@ def main():
             shape = fused_launch_shape(rows, cols, sz["pad"], int(round(fpl)))
             name = ("fw_blur_u8<%d, %s>" if shape["nkb"] > 11 else "fx_blur_u8<%d, %s>") % (shape["nkb"], "true")
             achieved = shape["flops"] / (k_ms * 1e-3) / 1e12
-            name2, traffic = pmc_traffic("blur", fpl, family)
+            name2, traffic = pmc_traffic("blur", fpl, family) if shape["nkb"] <= 11 else (None, None)      # counters are committed for fx_blur_u8 only
             side_ms = tm["col_ms"] / max(args.steps, 1)                # per step: the quirk's pre-pass (with the edge strips) and term kernels
             hbm_alg = FUSED_BYTES_PER_PX * px * fpl
             rec["roofline"] = {
