@@ -449,6 +449,30 @@ def test_fastboxblur_every_box_width_and_extremes(ctx):
             assert np.array_equal(got, want), "%s, box width %d" % (name, k)
 
 
+def test_fastboxblur_fuzz_time_boxed(ctx):
+    """random widths, heights, channel counts (1, 3, 4), box widths 1 .. 131, passes 1 .. 5, uniform and 0 / 255 images: byte-equal to
+    the oracle whichever kernels the library picks per direction (matrix-core pipelines, accumulator kernels).  About 25 s."""
+    import time
+    torch = _torch()
+    from oracle import oracle as O
+    rng = np.random.default_rng(20261007)
+    t_end = time.time() + 25.0
+    cases = 0
+    while time.time() < t_end or cases < 20:
+        ch = int(rng.choice([1, 3, 3, 4]))
+        w = int(rng.integers(1, 900))
+        if rng.random() < 0.6:
+            w = (w + 3) & ~3
+        h = int(rng.integers(1, 700))
+        k = int(rng.integers(1, 132))
+        p = int(rng.integers(1, 6))
+        img = rng.integers(0, 256, (h, w, ch), dtype=np.uint8) if rng.random() < 0.7 else (rng.integers(0, 2, (h, w, ch)) * 255).astype(np.uint8)
+        want = O.fastboxblur_u8(img, k, p)
+        got = ctx.fastboxblur(torch.from_numpy(img.copy()).cuda(), k, p).cpu().numpy()
+        assert np.array_equal(got, want), "w=%d h=%d channels=%d box=%d passes=%d: %d bytes differ" % (w, h, ch, k, p, int((got != want).sum()))
+        cases += 1
+
+
 def test_fastboxblur_writes_nothing_outside_the_image(ctx):
     """in place on a buffer with guard bytes either side, at a 4-byte-aligned and at an odd offset (the odd one runs the accumulator
     kernels: the matrix-core kernels want dword-aligned rows)"""
