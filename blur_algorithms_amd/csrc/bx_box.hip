@@ -414,7 +414,8 @@ hipError_t bx_launch_horz(hipStream_t st, const uint8_t* in, uint8_t* out, uint8
     constexpr int FILL = bx_horz_fill<NB>(P);
     g.ngroups = (g.h + 16 * NT - 1) / (16 * NT);
     // segments: four waves per SIMD in all (8K, k = 41, P = 3: 100 / 75 / 70 / 69 / 80 / 86 us with 4 / 6 / 10 / 15 / 20 / 30 segments of
-    // 270 row groups), none shorter than twice the bytes it takes to fill its pipeline
+    // 270 row groups; two groups of 16 rows per wave and half the waves: 84 .. 108 us), none shorter than twice the bytes it takes to
+    // fill its pipeline
     int nseg = (16 * num_cus + g.ngroups / 2) / g.ngroups;
     const int most = g.pitch / (2 * 16 * FILL);
     if (nseg > most) nseg = most;
