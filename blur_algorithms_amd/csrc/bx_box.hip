@@ -97,7 +97,9 @@ template <int NB> __device__ __forceinline__ v4i bx_band(int u, int m, int q, in
 // x 16 NT contiguous bytes -- and a 4 x 4 byte transpose inside the quad turns dword t into "column 16 qd + 4 t + p of the strip,
 // rows 4 q .. 4 q + 3": the window dword of tile t (tile t = the strip's columns 16 qd' + 4 t + p', any assignment of columns to
 // tiles will do).  Stores take the same road back.  Sweep p's tile of step s covers rows R0 - p DELTA + 16 s ..: the walk starts
-// P DELTA rows above the segment and the first P (W - 1) steps only fill the pipeline.
+// P DELTA rows above the segment and the first P (W - 1) steps only fill the pipeline.  (Skewing the sweeps by one step each, so
+// that the P products of an iteration are independent of each other, changed nothing in the horizontal kernel and cost 12 % in
+// this one: the chain is hidden by the other waves already.)
 template <int NB, int P, int NT>
 __global__ __launch_bounds__(256) void bx_vert_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int h, int pitch, int r, int s_band, uint32_t mul,
                                                       int seg_rows, int nstrips, int nwaves)
