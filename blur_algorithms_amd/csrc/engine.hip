@@ -1624,13 +1624,13 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     if (!p.mx_quirk) {
         TimedLaunch t(ctx, 1, nframes);
         hipLaunchKernelGGL(fx_prepass, dim3(strip_blocks * (fx_left_strips(pada) + g.nright) * nframes), dim3(256), 0, ctx->stream, d_src, nullptr, nullptr, nullptr, ctx->fx_strips, rows, cols,
-                           p.sz.pad, pada, 1, 1, 0, chunks_x, g.nright, strip_blocks);
+                           p.sz.pad, pada, 1, 1, 0, chunks_x, g.nright, strip_blocks, kFxSumRows);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (p.mx_quirk) {
         // scratch per frame: ints: srow_part [batches][rows][3], cpart [bands][3 cols], ccol [3 cols]; 64-bit: zpart [bands][batches][3];
         // floats: qrow [3][qrows], qcol [qpitch]
-        const int nbands = (rows + kFxSumRows - 1) / kFxSumRows, nbatches = (cols / 4 + 255) / 256;
+        const int band_rows = fx_band_rows(rows, cols), nbands = (rows + band_rows - 1) / band_rows, nbatches = (cols / 4 + 255) / 256;
         const size_t n_srow = static_cast<size_t>(nbatches) * rows * 3, n_cpart = static_cast<size_t>(nbands) * 3 * cols, n_ccol = static_cast<size_t>(3) * cols,
                      n_z = static_cast<size_t>(nbands) * nbatches * 3;
         auto up4 = [](size_t v) { return (v + 3) & ~static_cast<size_t>(3); };
@@ -1656,7 +1656,7 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         { TimedLaunch t(ctx, 1, nframes);
           const int n_alt = nbands * nbatches * nframes;
           hipLaunchKernelGGL(fx_prepass, dim3(n_alt + strip_blocks * (fx_left_strips(pada) + g.nright) * nframes), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, ctx->fx_strips, rows, cols,
-                             p.sz.pad, pada, nbands, nbatches, n_alt, chunks_x, g.nright, strip_blocks);
+                             p.sz.pad, pada, nbands, nbatches, n_alt, chunks_x, g.nright, strip_blocks, band_rows);
           HIP_TRY(ctx, hipGetLastError());
           const int nrb = (qrows + 255) / 256, nvb = (3 * cols + 255) / 256, ncb = (qpitch + 255) / 256;
           hipLaunchKernelGGL(fx_quirk_reduce, dim3(nrb + nvb + 1, nframes), dim3(256), 0, ctx->stream, srow, cpart, zpart, qrow, ccol, zsum, rows, cols, p.sz.pad, pada,

@@ -611,7 +611,9 @@ __device__ __forceinline__ void fx_edge_strips_body(const uint8_t* __restrict__ 
     }
 }
 
-constexpr int kFxSumRows = 32;          // image rows per band (packed 16-bit column sums: 32 x 3 x 255 < 65536)
+constexpr int kFxSumRows = 32;          // most image rows per band (packed 16-bit column sums: 32 x 3 x 255 < 65536); small frames take 16:
+                                        // twice the workgroups, each half as long (fx_band_rows)
+inline int fx_band_rows(int rows, int cols) { return static_cast<long long>(rows) * cols < 4000000ll ? 16 : kFxSumRows; }
 
 // sum over the 16 lanes of a DPP row, valid in every lane of the row
 __device__ __forceinline__ int fx_row16_sum(int v)
@@ -631,14 +633,14 @@ __device__ __forceinline__ int fx_row16_sum(int v)
 // sred[row][channel][lane]: lane l of every wave adds into slot l (one conflict-free ds_add_u32 per value: a same-address atomic the
 // compiler would turn into a serial loop over the lanes, and a DPP reduction costs twelve dependent instructions)
 __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
-                                                int rows, int cols, int pad, int nbands, int nbatches, int band, int batch, int f, int (*sred)[3][64])
+                                                int rows, int cols, int pad, int nbands, int nbatches, int band, int batch, int f, int (*sred)[3][64], int band_rows)
 {
     const int tid = threadIdx.x;
     const uint8_t* img = src + static_cast<size_t>(f) * rows * cols * 3;
-    const int groups = cols / 4, r0 = band * kFxSumRows, r1 = min(r0 + kFxSumRows, rows);
+    const int groups = cols / 4, r0 = band * band_rows, r1 = min(r0 + band_rows, rows);
     const int gi = batch * 256 + tid, x = 4 * gi;
     const bool act = gi < groups;
-    for (int i = tid; i < kFxSumRows * 3 * 64; i += 256) (&sred[0][0][0])[i] = 0;
+    for (int i = tid; i < band_rows * 3 * 64; i += 256) (&sred[0][0][0])[i] = 0;
     __syncthreads();
     const int flip = (pad & 1) ? -1 : 1;
     const bool plain = x > pad && x + 3 < cols - 1 - pad;                 // no pixel of the group is mirrored: weights +-1 by parity
@@ -734,13 +736,13 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
 // none with nyquist_quirk = 0) and the edge strips (strip_blocks x nstrips x frames workgroups, last in the grid: they fill the tail)
 __global__ __launch_bounds__(256) void fx_prepass(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
                                                   uint8_t* __restrict__ strips, int rows, int cols, int pad, int pada, int nbands, int nbatches, int n_alt, int chunks,
-                                                  int nright, int strip_blocks)
+                                                  int nright, int strip_blocks, int band_rows)
 {
     __shared__ int sred[kFxSumRows][3][64];
     int b = blockIdx.x;
     if (b < n_alt) {
         const int band = b % nbands, batch = (b / nbands) % nbatches, f = b / (nbands * nbatches);
-        fx_altsums_body(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred);
+        fx_altsums_body(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
     } else {
         b -= n_alt;
         const int nstrips = fx_left_strips(pada) + nright, bx = b % strip_blocks, sidx = (b / strip_blocks) % nstrips, f = b / (strip_blocks * nstrips);
