@@ -1310,7 +1310,8 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     // then reads one contiguous block instead of 16 bytes out of every row: 4000 x 6000 sigma 77.5: 593 -> 4xx us)
     p.gen_gshift = 0;
     if (u8c3 && !p.row->fast && !p.col->fast && !no_tile) {
-        const int C = colpass_lines(p.col->dev.n, rows, p.col_group, 3);
+        int C = colpass_lines(p.col->dev.n, rows, p.col_group, 3);
+        if (C < 1) C = colpass_lines(p.col->dev.n, rows, p.col_group, 0);        // very tall images: the column pass runs plane by plane (run_colpass_u8c3)
         if (C >= 1) {
             int g = 1;
             while ((1 << g) < 2 * C) ++g;
@@ -1355,9 +1356,11 @@ static int run_colpass_u8c3(blur_ctx* ctx, const float* planes, uint8_t* dst, in
             HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->work2), px * 3 * sizeof(float)));
             ctx->work2_bytes = px * 3 * sizeof(float);
         }
+        const size_t fstride = p.gen_gshift ? p.frame_elems : px * 3, cstride = fstride / 3;
         for (int f = 0; f < nframes; ++f) {
             for (int c = 0; c < 3; ++c)
-                if (int rc = launch_colpass<float, 1>(ctx, planes + (f * 3 + c) * px, ctx->work2 + c * px, rows, cols, p.sz.pad, *p.col, p.m_col, p.col_group)) return rc;
+                if (int rc = launch_colpass<float, 1>(ctx, planes + f * fstride + c * cstride, ctx->work2 + c * px, rows, cols, p.sz.pad, *p.col, p.m_col, p.col_group,
+                                                      p.gen_gshift ? 1 : 0)) return rc;
             const unsigned grid = static_cast<unsigned>(std::min<size_t>((px + 255) / 256, 2048u * 8));
             hipLaunchKernelGGL(interleave_kernel, dim3(grid), dim3(256), 0, ctx->stream, ctx->work2, dst + f * px * 3, static_cast<uint32_t>(px));
             HIP_TRY(ctx, hipGetLastError());
