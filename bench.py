@@ -195,51 +195,56 @@ def copy_bandwidth(ctx, mib=1024, reps=5):
     return ctx.copy_bandwidth(mib, reps)
 
 
-def box_config(args, torch, B):
+def box_leg(ctx, torch, dev, steps, warmup, copy=False):
     """BASELINE config 5: fastboxblur (call site Source.cpp:587), 8K RGB u8, box width 41, 3 passes, in place, device-resident"""
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(0)
-    ctx = B.BlurContext(0)
     c = CONFIGS["c5"]
     rows, cols, k, passes = c["rows"], c["cols"], 41, 3
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED0005)
     img = torch.randint(0, 256, (rows, cols, 3), dtype=torch.uint8, device=dev, generator=g)
-    for _ in range(max(args.warmup, 3)):
+    for _ in range(max(warmup, 3)):
         ctx.fastboxblur(img, k, passes)
     torch.cuda.synchronize(dev)
     # the contract's timed region without events (an event between two launches delays the second by about 3.5 us: 3 % here), then
     # the same K steps again with one event per step for the percentiles
     t0 = time.perf_counter()
-    for i in range(args.steps):
+    for i in range(steps):
         ctx.fastboxblur(img, k, passes)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
-    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     marks[0].record()
-    for i in range(args.steps):
+    for i in range(steps):
         ctx.fastboxblur(img, k, passes)
         marks[i + 1].record()
     torch.cuda.synchronize(dev)
-    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
     px = rows * cols
-    alg = 12 * passes * px
-    ms = 1e3 * dt / args.steps
-    achieved = alg / (ms * 1e-3) / 1e9
-    rec = {"metric": "megapixels/sec fastboxblur (8K RGB, 3-pass box k=41) at 1 GPU; % HBM roofline", "value": round(args.steps * px / 1e6 / dt, 1), "unit": "megapixels/s",
-           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+    ms = 1e3 * dt / steps
+    # The kernels as built move the image twice (all horizontal sweeps in one launch, all vertical ones in another): 12 B/px, and that
+    # is what `achieved` / `frac` price (nothing in the record can exceed 1).  BASELINE.md section 3 prices a P-pass box blur at
+    # 12 P B/px (every sweep reads and writes the image): kept as `two_pass_equiv`.
+    moved, equiv = 12 * px, 12 * passes * px
+    achieved = moved / (ms * 1e-3) / 1e9
+    rec = {"metric": "megapixels/sec fastboxblur (8K RGB, 3-pass box k=41) at 1 GPU; % HBM roofline", "value": round(steps * px / 1e6 / dt, 1), "unit": "megapixels/s",
+           "n_gpus": 1, "steps": steps, "warmup": warmup, "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "u8 (i8 matrix-core sums in i32, 24-bit multiply-high rounding per sweep)", "data": "synthetic",
            "config": {"workload": c["label"] + ", in place, device-resident", "frames_per_gpu": 1},
            "ms_per_step_gpu": percentiles(per_step),      # of a second pass of the same K steps with one event per step
-           # BASELINE.md section 3 prices a P-pass box blur at 12 P B/px (every sweep reads and writes the image); `frac` is against that
-           # figure.  The kernels as built move the image twice (all horizontal sweeps in one launch, all vertical ones in another):
-           # 12 B/px, reported as `moved`.
            "roofline": {"bound": "hbm", "kernel": "bx_margins_kernel + bx_horz_kernel<3,3,1> + bx_vert_kernel<1,3,4> (whole call)", "achieved": round(achieved, 1),
-                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": alg,
-                        "moved": {"bytes_per_launch": 12 * px, "achieved": round(12 * px / (ms * 1e-3) / 1e9, 1), "frac": round(12 * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}
-    if not args.no_copy:
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": moved,
+                        "two_pass_equiv": {"bytes_per_launch": equiv, "achieved": round(equiv / (ms * 1e-3) / 1e9, 1),
+                                           "frac": round(equiv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}
+    if copy:
         rec["roofline"]["copy_peak"] = round(copy_bandwidth(ctx), 1)
-    print(json.dumps(rec), flush=True)
+    return rec
+
+
+def box_config(args, torch, B):
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(0)
+    ctx = B.BlurContext(0)
+    print(json.dumps(box_leg(ctx, torch, dev, args.steps, args.warmup, copy=not args.no_copy)), flush=True)
 
 
 def reference_sweep(args, torch, B):
@@ -297,6 +302,160 @@ def reference_sweep(args, torch, B):
                       "all_agree": all(r.get("agrees", False) for r in ok), "sizes": rows_out}), flush=True)
 
 
+class Runner:
+    """fences and timed regions of one rank: W warm-up steps, then exactly K timed steps between two fences (barrier + synchronize
+    on both sides), the maximum over ranks"""
+
+    def __init__(self, torch, dist, dev, world, backend, ctx):
+        self.torch, self.dist, self.dev, self.world, self.backend, self.ctx = torch, dist, dev, world, backend, ctx
+
+    def fence(self):
+        self.torch.cuda.synchronize(self.dev)
+        if self.world > 1:
+            self.dist.barrier()
+        self.torch.cuda.synchronize(self.dev)
+
+    def settle(self, step, seconds):
+        """run the workload untimed for `seconds` (first touch of the workspaces, clock and power state)"""
+        if seconds <= 0:
+            return
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            for _ in range(4):
+                step()
+            self.torch.cuda.synchronize(self.dev)
+
+    def timed(self, step, steps, warmup, events, step_events=False):
+        """events: 0 none, 1 HIP events around every timed kernel launch, 2 around the dominant kernel only (blur_ctx_timing_enable);
+        step_events: one event per step as well.  Returns (seconds, per-kernel timing or None, per-step milliseconds)"""
+        torch, ctx = self.torch, self.ctx
+        for _ in range(warmup):
+            step()
+        self.fence()
+        if events:
+            ctx.timing_enable(2 if events == 2 else True)
+            ctx.timing(reset=True)
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if step_events else []
+        t0 = time.perf_counter()
+        if step_events:
+            marks[0].record()
+        for i in range(steps):
+            step()
+            if step_events:
+                marks[i + 1].record()
+        self.fence()
+        dt = time.perf_counter() - t0
+        tm = ctx.timing(reset=True) if events else None
+        ctx.timing_enable(False)
+        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)] if step_events else [1e3 * dt / steps]
+        t = torch.tensor([dt], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item()), tm, per_step
+
+
+def make_frames(torch, dev, g, kind, F, rows, cols):
+    """F device-resident frames: i.i.d. uniform u8 or a committed natural-image crop tiled to the frame size"""
+    if kind == "synthetic":
+        return torch.randint(0, 256, (F, rows, cols, 3), dtype=torch.uint8, device=dev, generator=g)
+    import numpy as np
+    tile = np.load(os.path.join(ROOT, "tests", "golden", "img_collage_top.npz"))["src"]
+    reps = (-(-rows // tile.shape[0]), -(-cols // tile.shape[1]), 1)
+    one = torch.from_numpy(np.ascontiguousarray(np.tile(tile, reps)[:rows, :cols])).to(dev)
+    return torch.stack([torch.roll(one, shifts=(17 * i, 31 * i), dims=(0, 1)) for i in range(F)]).contiguous()
+
+
+def engine_text(B, family, rows, cols, sz, F):
+    """what ran, in words (config.engine)"""
+    import ctypes as C
+    lib = B._lib.load()
+    if family == 2:
+        n_row, n_col = lib.blur_wr_length(cols + 2 * sz["pad"], 0), lib.blur_wr_length(rows + 2 * sz["pad"], 1)
+        return "wave-resident FFT kernels, columns first, engine FFT lengths %d (rows) / %d (columns)" % (n_row, n_col)
+    if family == 4:
+        lib.blur_mx_window_blocks.argtypes = [C.c_int]
+        lib.blur_mx_window_blocks.restype = C.c_int
+        nkb = lib.blur_mx_window_blocks(sz["pad"])
+        return ("%s: both passes as banded Toeplitz products on v_mfma_f32_32x32x16_f16 (window %d positions for %d taps, taps and "
+                "intermediate in hi + lo binary16 halves, f32 accumulation), Nyquist-slot quirk as rank-one terms"
+                % (FAMILY_NAME[family], 16 * nkb, sz["kSize"]))
+    if family == 6:
+        shape = fused_launch_shape(rows, cols, sz["pad"], F)
+        return ("%s: row pass, register hand-off, column pass and byte emission in one launch on v_mfma_f32_32x32x16_f16 (window %d positions "
+                "for %d taps; taps and intermediate in hi + lo binary16 halves, f32 accumulation; no intermediate in memory), Nyquist-slot quirk as "
+                "rank-one terms from an integer pre-pass over the image" % (FAMILY_NAME[family], 16 * shape["nkb"], sz["kSize"]))
+    return FAMILY_NAME.get(family, "?") + " at the reference's FFT lengths"
+
+
+def roofline_record(family, tm, steps, rows, cols, sz, copy_gbs):
+    """the `roofline` object for the dominant kernel of a Gaussian leg from the per-kernel HIP events of its instrumented pass"""
+    px = rows * cols
+    if family == 6 and tm and tm["row_launches"]:
+        # One launch does both passes and keeps the intermediate on chip: the kernel is bound by the matrix pipe, not by HBM.
+        # achieved = the matrix instructions the launch executes x 32768 flop / its average duration (HIP events on the launch
+        # stream over the K steps of the instrumented pass); the HBM side is reported with what the kernel has to move (6 B/px).
+        k_ms = tm["row_ms"] / tm["row_launches"]
+        fpl = tm["row_frames"] / tm["row_launches"]
+        shape = fused_launch_shape(rows, cols, sz["pad"], int(round(fpl)))
+        name = ("fw_blur_u8<%d, %s>" if shape["nkb"] > 11 else "fx_blur_u8<%d, %s>") % (shape["nkb"], "true")
+        achieved = shape["flops"] / (k_ms * 1e-3) / 1e12
+        name2, traffic = pmc_traffic("blur", fpl, family) if shape["nkb"] <= 11 else (None, None)      # counters are committed for fx_blur_u8 only
+        side_ms = tm["col_ms"] / max(steps, 1)                     # per step: the quirk's pre-pass (with the edge strips) and term kernel
+        hbm_alg = FUSED_BYTES_PER_PX * px * fpl
+        rl = {
+            "bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+            "avg_launch_ms": {name: round(k_ms, 4), "side kernels per step (the quirk's pre-pass with the edge strips, its term kernel; instrumented pass)": round(side_ms, 4)},
+            "frames_per_launch": fpl,
+            "flops_per_launch": shape["flops"], "mfma_instructions_per_launch": shape["mfma_instructions"], "tasks": shape["tasks"],
+            "useful_flop_frac": round((2 * sz["pad"] + 1) / (16.0 * shape["nkb"]), 4),     # taps / window positions the products cover
+            "hbm": {"alg_bytes_per_launch": hbm_alg, "achieved": round(hbm_alg / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(hbm_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "two_pass_alg_bytes_per_launch": 2 * ALG_BYTES_PER_PX_KERNEL * px * fpl,
+                    "two_pass_frac": round(2 * ALG_BYTES_PER_PX_KERNEL * px * fpl / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+        }
+        if copy_gbs:
+            rl["hbm"]["copy_peak"] = round(copy_gbs, 1)
+        return rl
+    if tm and tm["row_launches"] and tm["col_launches"]:
+        row_ms = tm["row_ms"] / tm["row_launches"]
+        col_ms = tm["col_ms"] / tm["col_launches"]
+        fpl = tm["row_frames"] / tm["row_launches"]            # frames one launch covers
+        role, dur = ("col", col_ms) if col_ms >= row_ms else ("row", row_ms)
+        name, traffic = pmc_traffic(role, fpl, family)
+        alg = ALG_BYTES_PER_PX_KERNEL * px * fpl
+        achieved = alg / (dur * 1e-3) / 1e9
+        rl = {
+            "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "avg_launch_ms": {pmc_traffic("row", fpl, family)[0]: round(row_ms, 4), pmc_traffic("col", fpl, family)[0]: round(col_ms, 4)},
+            "frames_per_launch": fpl,
+            "alg_bytes_per_launch": alg,
+        }
+        if copy_gbs:
+            rl["copy_peak"] = round(copy_gbs, 1)           # measured streaming copy on this box, GB/s
+            rl["frac_of_copy"] = round(achieved / copy_gbs, 4)
+        return rl
+    return None
+
+
+def config_record(B, ctx, c, elapsed, tm, steps, copy_gbs):
+    """compact record of one BASELINE configuration's short leg (the `configs` object of the default run)"""
+    rows, cols, sigma, F = c["rows"], c["cols"], c["sigma"], c["frames"]
+    px = rows * cols
+    sz = B.pffft_sizing(rows, cols, sigma)
+    family = ctx.last_family()
+    rec = {"workload": "%s, %d frames per step, device-resident" % (c["label"], F), "value": round(steps * F * px / 1e6 / elapsed, 1), "unit": "megapixels/s",
+           "ms_per_step": round(1e3 * elapsed / steps, 4),
+           "frame_roofline_frac": round(steps * F * 2 * ALG_BYTES_PER_PX_KERNEL * px / elapsed / 1e9 / HBM_PEAK_GBS, 4),
+           "engine": FAMILY_NAME.get(family, "?")}
+    rl = roofline_record(family, tm, steps, rows, cols, sz, None)
+    if rl:
+        rec.update({"kernel": rl["kernel"], "bound": rl["bound"], "frac": rl["frac"], "achieved": rl["achieved"], "achieved_unit": rl["unit"],
+                    "avg_launch_ms": rl["avg_launch_ms"]})
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,6 +483,7 @@ def main():
     ap.add_argument("--no-step-events", action="store_true", help="do not record one event per step in the timed region (no ms_per_step_gpu percentiles)")
     ap.add_argument("--no-natural", action="store_true", help="skip the second (natural-image) timed run")
     ap.add_argument("--no-copy", action="store_true", help="skip the streaming-copy bandwidth measurement")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short C2 / C3 / C5 legs of the default run (the `configs` object)")
     ap.add_argument("--settle", type=float, default=0.4,
                     help="seconds of the same workload run BEFORE the W warm-up steps (untimed): first-touch of the workspaces, "
                          "clock and power state; the first few milliseconds after an idle gap run 5-10 %% slower (DESIGN.md)")
@@ -397,115 +557,86 @@ def main():
 
     g = torch.Generator(device=dev)
     g.manual_seed(0x5EED0000 + rank)
-
-    def make_frames(kind):
-        if kind == "synthetic":
-            return torch.randint(0, 256, (F, rows, cols, 3), dtype=torch.uint8, device=dev, generator=g)
-        import numpy as np
-        tile = np.load(os.path.join(ROOT, "tests", "golden", "img_collage_top.npz"))["src"]
-        reps = (-(-rows // tile.shape[0]), -(-cols // tile.shape[1]), 1)
-        one = torch.from_numpy(np.ascontiguousarray(np.tile(tile, reps)[:rows, :cols])).to(dev)
-        return torch.stack([torch.roll(one, shifts=(17 * i, 31 * i), dims=(0, 1)) for i in range(F)]).contiguous()
-
-    frames = make_frames(args.data)
-    out = torch.empty_like(frames)
     ctx = B.BlurContext(local)
     wr = {"auto": None, "on": True, "off": False}[args.wave_resident]
     eng = None if args.engine == "auto" else args.engine
     if wr is not None and eng is None:
         eng = "wave-resident" if wr else "rows-first"          # the round-2 A/B switch still selects an FFT family
+    run = Runner(torch, dist, dev, world, args.dist_backend, ctx)
 
-    def fence():
-        torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+    frames = make_frames(torch, dev, g, args.data, F, rows, cols)
+    out = torch.empty_like(frames)
 
-    def timed_run(src, steps, warmup, events, engine="default", step_events=False):
-        """W warm-up steps, then exactly `steps` timed steps between two fences.  events: 0 none, 1 HIP events around every timed
-        kernel launch, 2 around the dominant kernel only (blur_ctx_timing_enable); step_events: one event per step as well"""
+    def step_on(src, dst, sg, engine="default"):
         def step():
-            ctx.pffft_(src, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch, wave_resident=wr, engine=(eng if engine == "default" else engine))
-        for _ in range(warmup):
-            step()
-        fence()
-        if events:
-            ctx.timing_enable(2 if events == 2 else True)
-            ctx.timing(reset=True)
-        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)] if step_events else []
-        t0 = time.perf_counter()
-        if step_events:
-            marks[0].record()
-        for i in range(steps):
-            step()
-            if step_events:
-                marks[i + 1].record()
-        fence()
-        dt = time.perf_counter() - t0
-        tm = ctx.timing(reset=True) if events else None
-        ctx.timing_enable(False)
-        per_step = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)] if step_events else [1e3 * dt / steps]
-        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.dist_backend == "nccl" else "cpu")
-        if world > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item()), tm, per_step
+            ctx.pffft_(src, sg, out=dst, col_group=args.col_group, frames_per_launch=args.frames_per_launch, wave_resident=wr, engine=(eng if engine == "default" else engine))
+        return step
 
-    if args.settle > 0:                                    # untimed, before the contract's W warm-up steps
-        t_end = time.perf_counter() + args.settle
-        while time.perf_counter() < t_end:
-            for _ in range(4):
-                ctx.pffft_(frames, sigma, out=out, col_group=args.col_group, frames_per_launch=args.frames_per_launch, wave_resident=wr, engine=eng)
-            torch.cuda.synchronize(dev)
+    step = step_on(frames, out, sigma)
+    run.settle(step, args.settle)                          # untimed, before the contract's W warm-up steps
     # An event between two kernels keeps the second from starting while the first drains (the fused engine's step is one big kernel
-    # and three small ones; measured per step on one box: 0.353 ms without events, 0.361 with the fused kernel's pair, 0.367 with
-    # every kernel's and one per step).  So the contract's timed region carries no events, and a second pass of the same K steps
+    # and the quirk's side kernels; measured per step on one box: 0.353 ms without events, 0.361 with the fused kernel's pair, 0.367
+    # with every kernel's and one per step).  So the contract's timed region carries no events, and a second pass of the same K steps
     # right after it carries all of them: kernel durations for `roofline` (they agree with rocprofv3's kernel trace) and the
     # per-step percentiles (`instrumented_pass`).
     two_regions = not args.no_events
-    elapsed, tm, per_step = timed_run(frames, args.steps, args.warmup, 0, step_events=not two_regions and not args.no_step_events)
+    elapsed, tm, per_step = run.timed(step, args.steps, args.warmup, 0, step_events=not two_regions and not args.no_step_events)
     instrumented_ms = None
     if two_regions:
-        inst_elapsed, tm, per_step = timed_run(frames, args.steps, 0, 1, step_events=not args.no_step_events)
+        inst_elapsed, tm, per_step = run.timed(step, args.steps, 0, 1, step_events=not args.no_step_events)
         instrumented_ms = 1e3 * inst_elapsed / args.steps
+    family = ctx.last_family()
     natural = None
     if args.data == "synthetic" and not args.no_natural:
-        nat_elapsed, _, _ = timed_run(make_frames("natural"), args.steps, max(args.warmup, 10), False)
-        natural = nat_elapsed
+        # the same workload on natural-image frames, with the same settle as the synthetic leg (round 3 ran it right after the host had
+        # built the frames, with ten warm-up steps = 3.6 ms: the first ~30 ms after an idle gap run slow)
+        nat = make_frames(torch, dev, g, "natural", F, rows, cols)
+        nstep = step_on(nat, out, sigma)
+        run.settle(nstep, args.settle)
+        natural, _, _ = run.timed(nstep, args.steps, args.warmup, 0)
+        del nat
     # the same workload on the FFT kernels (the path north_star describes), a shorter run, for the record
     fft_value = None
     if args.engine == "auto" and args.wave_resident == "auto" and not args.no_natural:
         fsteps = max(3, args.steps // 2)
-        fft_elapsed, _, _ = timed_run(frames, fsteps, 2, False, engine="fft")
+        fft_elapsed, _, _ = run.timed(step_on(frames, out, sigma, engine="fft"), fsteps, 2, 0)
         fft_value = world * fsteps * F * rows * cols / 1e6 / fft_elapsed
-        timed_run(frames, 1, 0, False)                      # leave the context on the default engine (last_family below)
     copy_gbs = None if (args.no_copy or rank != 0) else copy_bandwidth(ctx)
+
+    # BASELINE.json's other single-GPU configurations, short legs of the same K steps (rank 0 of a 1-GPU run only; no CPU leg):
+    # the driver runs `python bench.py --gpus 1` only, so this is where C2 / C3 / C5 reach its record
+    configs = None
+    if world == 1 and args.config == "metric" and args.engine == "auto" and args.wave_resident == "auto" and not args.no_configs \
+            and (rows, cols, sigma) == (cfg["rows"], cfg["cols"], cfg["sigma"]):
+        configs = {}
+        for name in ("c2", "c3"):
+            c = CONFIGS[name]
+            cf = make_frames(torch, dev, g, "synthetic", c["frames"], c["rows"], c["cols"])
+            co = torch.empty_like(cf)
+            cstep = step_on(cf, co, c["sigma"])
+            run.settle(cstep, min(args.settle, 0.2))
+            c_el, _, _ = run.timed(cstep, args.steps, args.warmup, 0)
+            _, c_tm, _ = run.timed(cstep, args.steps, 0, 1)
+            configs[name] = config_record(B, ctx, c, c_el, c_tm, args.steps, copy_gbs)
+            del cf, co
+        b5 = box_leg(ctx, torch, dev, args.steps, args.warmup)
+        configs["c5"] = {"workload": b5["config"]["workload"], "value": b5["value"], "unit": "megapixels/s", "ms_per_step": b5["ms_per_step"],
+                         "kernel": b5["roofline"]["kernel"], "bound": "hbm", "frac": b5["roofline"]["frac"],
+                         "achieved_GBs": b5["roofline"]["achieved"], "two_pass_equiv_frac": b5["roofline"]["two_pass_equiv"]["frac"]}
+    # the cold number: no settle, 5 warm-up steps, then the first K steps after the GPU has been idle for a second (what a caller
+    # sees who blurs one batch now and then; `value` is the steady state of back-to-back batches)
+    cold = None
+    if args.data == "synthetic" and not args.no_natural:
+        run.fence()
+        time.sleep(1.0)
+        cold, _, _ = run.timed(step, args.steps, 5, 0)
+    else:
+        run.timed(step, 1, 0, 0)                            # leave the context on the default engine
 
     if rank == 0:
         px = rows * cols
         mp_total = world * args.steps * F * px / 1e6
         sz = B.pffft_sizing(rows, cols, sigma)
-        import ctypes as C
-        lib = B._lib.load()
-        lib.blur_debug_last_family.argtypes = [C.c_void_p]
-        lib.blur_debug_last_family.restype = C.c_int
-        family = lib.blur_debug_last_family(ctx._h)
-        if family == 2:
-            n_row, n_col = lib.blur_wr_length(cols + 2 * sz["pad"], 0), lib.blur_wr_length(rows + 2 * sz["pad"], 1)
-            engine = "wave-resident FFT kernels, columns first, engine FFT lengths %d (rows) / %d (columns)" % (n_row, n_col)
-        elif family == 4:
-            lib.blur_mx_window_blocks.argtypes = [C.c_int]
-            lib.blur_mx_window_blocks.restype = C.c_int
-            nkb = lib.blur_mx_window_blocks(sz["pad"])
-            engine = ("%s: both passes as banded Toeplitz products on v_mfma_f32_32x32x16_f16 (window %d positions for %d taps, taps and "
-                      "intermediate in hi + lo binary16 halves, f32 accumulation), Nyquist-slot quirk as rank-one terms"
-                      % (FAMILY_NAME[family], 16 * nkb, sz["kSize"]))
-        elif family == 6:
-            shape = fused_launch_shape(rows, cols, sz["pad"], F)
-            engine = ("%s: row pass, register hand-off, column pass and byte emission in one launch on v_mfma_f32_32x32x16_f16 (window %d positions "
-                      "for %d taps; taps and intermediate in hi + lo binary16 halves, f32 accumulation; no intermediate in memory), Nyquist-slot quirk as "
-                      "rank-one terms from an integer pre-pass over the image" % (FAMILY_NAME[family], 16 * shape["nkb"], sz["kSize"]))
-        else:
-            engine = FAMILY_NAME.get(family, "?") + " at the reference's FFT lengths"
         rec = {
             "metric": baseline_metric(),
             "value": round(mp_total / elapsed, 1),
@@ -523,7 +654,7 @@ def main():
                 "workload": "%s: %dx%d RGB u8 frames, sigma=%g (kSize %d), reference FFT row/col lengths %d/%d, %d frames per GPU per step, device-resident"
                             % (cfg["label"] if (rows, cols, sigma) == (cfg["rows"], cfg["cols"], cfg["sigma"]) else "custom", cols, rows, sigma, sz["kSize"],
                                sz["N1"], sz["N0"], F),
-                "engine": engine,
+                "engine": engine_text(B, family, rows, cols, sz, F),
                 "frames_per_gpu": F,
                 "sharding": "frames over ranks, no data-path collective",
             },
@@ -534,56 +665,18 @@ def main():
             # the second pass of the same K steps with HIP events around every kernel and every step (they cost about 3.5 us each)
             rec["instrumented_pass"] = {"ms_per_step": round(instrumented_ms, 4), "value": round(mp_total / (instrumented_ms * 1e-3 * args.steps), 1)}
         if natural is not None:
-            rec["value_natural"] = round(mp_total / natural, 1)      # same workload on natural-image frames (tests/golden crop, tiled)
+            rec["value_natural"] = round(mp_total / natural, 1)      # same workload on natural-image frames (tests/golden crop, tiled), same settle
+        if cold is not None:
+            rec["value_cold"] = round(mp_total / cold, 1)            # no settle: 1 s idle, 5 warm-up steps, the first K steps
         if fft_value is not None:
             rec["value_fft_kernels"] = round(fft_value, 1)           # same workload, --engine fft (wave-resident FFT kernels)
-        frame_bytes = 2 * ALG_BYTES_PER_PX_KERNEL * px
         # the metric's "% HBM roofline" as BASELINE.md section 3 defines it: 30 algorithmic B/px of the two-pass algorithm / whole-job time / 8 TB/s
-        rec["frame_roofline_frac"] = round((world * args.steps * F * frame_bytes / elapsed / 1e9) / (HBM_PEAK_GBS * world), 4)
-        if family == 6 and tm and tm["row_launches"]:
-            # One launch does both passes and keeps the intermediate on chip: the kernel is bound by the matrix pipe, not by HBM.
-            # achieved = the matrix instructions the launch executes x 32768 flop / its average duration (HIP events on the launch
-            # stream over the K steps of the instrumented pass); the HBM side is reported with what the kernel has to move (6 B/px).
-            k_ms = tm["row_ms"] / tm["row_launches"]
-            fpl = tm["row_frames"] / tm["row_launches"]
-            shape = fused_launch_shape(rows, cols, sz["pad"], int(round(fpl)))
-            name = ("fw_blur_u8<%d, %s>" if shape["nkb"] > 11 else "fx_blur_u8<%d, %s>") % (shape["nkb"], "true")
-            achieved = shape["flops"] / (k_ms * 1e-3) / 1e12
-            name2, traffic = pmc_traffic("blur", fpl, family) if shape["nkb"] <= 11 else (None, None)      # counters are committed for fx_blur_u8 only
-            side_ms = tm["col_ms"] / max(args.steps, 1)                # per step: the quirk's pre-pass (with the edge strips) and term kernels
-            hbm_alg = FUSED_BYTES_PER_PX * px * fpl
-            rec["roofline"] = {
-                "bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                "avg_launch_ms": {name: round(k_ms, 4), "side kernels per step (fx_prepass, fx_quirk_reduce, fx_quirk_cols; instrumented pass)": round(side_ms, 4)},
-                "frames_per_launch": fpl,
-                "flops_per_launch": shape["flops"], "mfma_instructions_per_launch": shape["mfma_instructions"], "tasks": shape["tasks"],
-                "useful_flop_frac": round((2 * sz["pad"] + 1) / (16.0 * shape["nkb"]), 4),     # taps / window positions the products cover
-                "hbm": {"alg_bytes_per_launch": hbm_alg, "achieved": round(hbm_alg / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(hbm_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                        "two_pass_alg_bytes_per_launch": 2 * ALG_BYTES_PER_PX_KERNEL * px * fpl,
-                        "two_pass_frac": round(2 * ALG_BYTES_PER_PX_KERNEL * px * fpl / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-            }
-            if copy_gbs:
-                rec["roofline"]["hbm"]["copy_peak"] = round(copy_gbs, 1)
-        elif tm and tm["row_launches"] and tm["col_launches"]:
-            row_ms = tm["row_ms"] / tm["row_launches"]
-            col_ms = tm["col_ms"] / tm["col_launches"]
-            fpl = tm["row_frames"] / tm["row_launches"]            # frames one launch covers
-            role, dur = ("col", col_ms) if col_ms >= row_ms else ("row", row_ms)
-            name, traffic = pmc_traffic(role, fpl, family)
-            alg = ALG_BYTES_PER_PX_KERNEL * px * fpl
-            achieved = alg / (dur * 1e-3) / 1e9
-            rec["roofline"] = {
-                "bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "avg_launch_ms": {pmc_traffic("row", fpl, family)[0]: round(row_ms, 4), pmc_traffic("col", fpl, family)[0]: round(col_ms, 4)},
-                "frames_per_launch": fpl,
-                "alg_bytes_per_launch": alg,
-            }
-            if copy_gbs:
-                rec["roofline"]["copy_peak"] = round(copy_gbs, 1)           # measured streaming copy on this box, GB/s
-                rec["roofline"]["frac_of_copy"] = round(achieved / copy_gbs, 4)
+        rec["frame_roofline_frac"] = round((world * args.steps * F * 2 * ALG_BYTES_PER_PX_KERNEL * px / elapsed / 1e9) / (HBM_PEAK_GBS * world), 4)
+        rl = roofline_record(family, tm, args.steps, rows, cols, sz, copy_gbs)
+        if rl:
+            rec["roofline"] = rl
+        if configs:
+            rec["configs"] = configs
         if world == 1 and not args.no_cpu:
             rec["cpu_baseline"] = cpu_baseline(rows, cols, sigma)
         print(json.dumps(rec), flush=True)

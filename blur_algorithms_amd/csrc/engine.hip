@@ -45,12 +45,13 @@ namespace {
 constexpr int kThreads = 256;
 constexpr size_t kLdsLimit = 160 * 1024;
 
-// Blocks b and b+8 share an XCD (and its L2).  Give each XCD a contiguous run of work
-// items so that neighbours (which touch the same 128-byte lines) meet in one L2.
-__device__ __forceinline__ int xcd_contiguous(int b, int nwg)
+// Blocks b and b + nx share an XCD (and its L2; nx = hipDeviceAttributeNumberOfXccs, 8 on MI355X).  Give each XCD a contiguous
+// run of work items so that neighbours (which touch the same 128-byte lines) meet in one L2.
+__device__ __forceinline__ int xcd_contiguous(int b, int nwg, int nx)
 {
-    const int q = nwg >> 3, r = nwg & 7, x = b & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (b >> 3);
+    if (nx < 1) nx = 8;
+    const int q = nwg / nx, r = nwg - q * nx, x = b % nx;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + b / nx;
 }
 
 // reflect-101 source index of padded position p (Source.cpp:525-529); -1 = trailing zero
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(T) void rowpass_kernel(const InT* __restrict__ src,
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float2* z = reinterpret_cast<float2*>(smem);
-    const int item = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int item = xcd_contiguous(blockIdx.x, gridDim.x, plan.nxcd);
     const int pair = item / CH, c = item - pair * CH;
     const int r0 = 2 * pair;
     const bool two = r0 + 1 < rows;
@@ -133,7 +134,7 @@ __global__ __launch_bounds__(T) void colpass_kernel(const float* __restrict__ pl
     const int n = plan.n;
     const int zs = line_stride(n);
     uint8_t* stage = reinterpret_cast<uint8_t*>(z + static_cast<size_t>(C) * zs);   // [rows][G][CH] bytes (u8 output only)
-    const int strip = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int strip = xcd_contiguous(blockIdx.x, gridDim.x, plan.nxcd);
     const int x0 = strip * G;
 
     for (int c = 0; c < CH; ++c) {
@@ -664,6 +665,10 @@ struct blur_ctx {
     std::map<std::tuple<int, int, int, int, int, uint64_t>, MxTables> mx_tables;   // (ksize | -1, pad, nkb, n_row, n_col, sigma bits | hash)
     uint8_t* fx_strips = nullptr;   // fused kernel: the edge chunks' windows with the mirrored pixels in place
     size_t fx_strips_bytes = 0;
+    int* fx_acc = nullptr;          // fused kernel, quirk: two sets of integer accumulators + the parts of Z (run_fx_u8c3)
+    size_t fx_acc_ints = 0, fx_z_count = 0;
+    size_t fx_acc_clear[2] = { 0, 0 };   // leading ints of each set known to be zero
+    int fx_acc_phase = 0;
     int* mx_sums = nullptr;
     size_t mx_sums_bytes = 0;
     float* mx_terms = nullptr;
@@ -875,6 +880,8 @@ static int launch_rowpass(blur_ctx* ctx, const InT* src, float* planes, int rows
                           const DevicePlan& plan, const float* mperm, int gshift = 0)
 {
     const size_t lds = row_lds_bytes(plan.dev.n);
+    DevPlan dv = plan.dev;
+    dv.nxcd = ctx->num_xcds;
     if (lds > kLdsLimit) return fail(ctx, BLUR_ERR_UNSUPPORTED, "row FFT length exceeds LDS capacity");
     const int grid = ((rows + 1) / 2) * CH;
     // long lines leave room for one or two workgroups per CU only: four times the threads then (the passes are loops over
@@ -883,13 +890,13 @@ static int launch_rowpass(blur_ctx* ctx, const InT* src, float* planes, int rows
     TimedLaunch t(ctx, 0);
     if (threads == 1024) {
         if (int rc = set_lds(ctx, rowpass_kernel<InT, CH, 1024>, lds)) return rc;
-        hipLaunchKernelGGL((rowpass_kernel<InT, CH, 1024>), dim3(grid), dim3(1024), lds, ctx->stream, src, planes, rows, cols, pad, plan.dev, plan.d_tw, mperm, gshift);
+        hipLaunchKernelGGL((rowpass_kernel<InT, CH, 1024>), dim3(grid), dim3(1024), lds, ctx->stream, src, planes, rows, cols, pad, dv, plan.d_tw, mperm, gshift);
     } else if (threads == 512) {
         if (int rc = set_lds(ctx, rowpass_kernel<InT, CH, 512>, lds)) return rc;
-        hipLaunchKernelGGL((rowpass_kernel<InT, CH, 512>), dim3(grid), dim3(512), lds, ctx->stream, src, planes, rows, cols, pad, plan.dev, plan.d_tw, mperm, gshift);
+        hipLaunchKernelGGL((rowpass_kernel<InT, CH, 512>), dim3(grid), dim3(512), lds, ctx->stream, src, planes, rows, cols, pad, dv, plan.d_tw, mperm, gshift);
     } else {
         if (int rc = set_lds(ctx, rowpass_kernel<InT, CH>, lds)) return rc;
-        hipLaunchKernelGGL((rowpass_kernel<InT, CH>), dim3(grid), dim3(kThreads), lds, ctx->stream, src, planes, rows, cols, pad, plan.dev, plan.d_tw, mperm, gshift);
+        hipLaunchKernelGGL((rowpass_kernel<InT, CH>), dim3(grid), dim3(kThreads), lds, ctx->stream, src, planes, rows, cols, pad, dv, plan.d_tw, mperm, gshift);
     }
     HIP_TRY(ctx, hipGetLastError());
     return BLUR_OK;
@@ -900,18 +907,20 @@ static int launch_colpass_c(blur_ctx* ctx, const float* planes, OutT* dst, int r
                             const DevicePlan& plan, const float* mperm, int strips)
 {
     const size_t lds = col_lds_bytes(plan.dev.n, C, rows, sizeof(OutT) == 1 ? CH : 0);
+    DevPlan dv = plan.dev;
+    dv.nxcd = ctx->num_xcds;
     const int grid = (cols + 2 * C - 1) / (2 * C);
     const int threads = generic_threads(lds, true);
     TimedLaunch t(ctx, 1);
     if (threads == 1024) {
         if (int rc = set_lds(ctx, colpass_kernel<OutT, CH, C, 1024>, lds)) return rc;
-        hipLaunchKernelGGL((colpass_kernel<OutT, CH, C, 1024>), dim3(grid), dim3(1024), lds, ctx->stream, planes, dst, rows, cols, pad, plan.dev, plan.d_tw, mperm, strips);
+        hipLaunchKernelGGL((colpass_kernel<OutT, CH, C, 1024>), dim3(grid), dim3(1024), lds, ctx->stream, planes, dst, rows, cols, pad, dv, plan.d_tw, mperm, strips);
     } else if (threads == 512) {
         if (int rc = set_lds(ctx, colpass_kernel<OutT, CH, C, 512>, lds)) return rc;
-        hipLaunchKernelGGL((colpass_kernel<OutT, CH, C, 512>), dim3(grid), dim3(512), lds, ctx->stream, planes, dst, rows, cols, pad, plan.dev, plan.d_tw, mperm, strips);
+        hipLaunchKernelGGL((colpass_kernel<OutT, CH, C, 512>), dim3(grid), dim3(512), lds, ctx->stream, planes, dst, rows, cols, pad, dv, plan.d_tw, mperm, strips);
     } else {
         if (int rc = set_lds(ctx, colpass_kernel<OutT, CH, C>, lds)) return rc;
-        hipLaunchKernelGGL((colpass_kernel<OutT, CH, C>), dim3(grid), dim3(kThreads), lds, ctx->stream, planes, dst, rows, cols, pad, plan.dev, plan.d_tw, mperm, strips);
+        hipLaunchKernelGGL((colpass_kernel<OutT, CH, C>), dim3(grid), dim3(kThreads), lds, ctx->stream, planes, dst, rows, cols, pad, dv, plan.d_tw, mperm, strips);
     }
     HIP_TRY(ctx, hipGetLastError());
     return BLUR_OK;
@@ -1100,7 +1109,8 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
         }
         if (e != hipSuccess) {
             release();
-            ctx->err = std::string("matrix-core tables: ") + hipGetErrorString(e);
+            (void)hipGetLastError();          // clear it: under AUTO the caller falls back to another engine, whose first launch check would pick it up
+            if (!quiet) ctx->err = std::string("matrix-core tables: ") + hipGetErrorString(e);
             return BLUR_ERR_HIP;
         }
         (ax ? t.dc : t.dr) = m0 - mh;
@@ -1190,7 +1200,8 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
             (static_cast<long long>(rows) * cols < 6000000ll || (small_fft && fe->nkb >= 23))) fe = nullptr;
         const char* why = nullptr;
         if (!fe) why = "fused matrix-core engine: no kernel instantiated for this pad";
-        else if (static_cast<long long>(rows) * cols * 3 >= (1ll << 32)) why = "fused matrix-core engine: frame too large for 32-bit offsets";
+        // (0xfffffff0 is the offset the kernels give a dropped store: it must lie outside the frame's buffer resource)
+        else if (static_cast<long long>(rows) * cols * 3 > 0xfffffff0ll) why = "fused matrix-core engine: frame too large for 32-bit offsets";
         else if ((cols & 3) != 0) why = "fused matrix-core engine: the image width must be a multiple of 4";
         else if (!ptrs_aligned) why = "fused matrix-core engine: frame pointers must be 4-byte aligned";
         if (why && choice == BLUR_ENGINE_FUSED) return fail(ctx, BLUR_ERR_UNSUPPORTED, why);
@@ -1511,6 +1522,7 @@ int blur_ctx_destroy(blur_ctx* ctx)
     }
     for (auto& lt : ctx->lines_tables) (void)hipFree(lt.dev);
     if (ctx->fx_strips) (void)hipFree(ctx->fx_strips);
+    if (ctx->fx_acc) (void)hipFree(ctx->fx_acc);
     if (ctx->mx_sums) (void)hipFree(ctx->mx_sums);
     if (ctx->mx_terms) (void)hipFree(ctx->mx_terms);
     if (ctx->work) (void)hipFree(reinterpret_cast<char*>(ctx->work) - kWorkGuard);
@@ -1646,11 +1658,10 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         HIP_TRY(ctx, hipMemcpyAsync(ctx->work, d_src, px * 3 * nframes, hipMemcpyDeviceToDevice, ctx->stream));
         d_src = reinterpret_cast<const uint8_t*>(ctx->work);
     }
-    const int nkb = p.fx->nkb, pada = 8 * (nkb - 2), nt = (nkb - 1) / 2;
+    const int nkb = p.fx->nkb, pada = 8 * (nkb - 2);
     FxGeom g{ rows, cols, p.sz.pad, nframes, 0, (rows + 31) / 32, fx_right_strips(cols, pada), ctx->num_xcds };
     g.aligned = ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 3) == 0) ? 1 : 0;
     if (!g.aligned) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: frame pointers must be 4-byte aligned");
-    const int qrows = 32 * (g.ntiles + nt), qpitch = (3 * cols + 31) & ~31;
     {   // the edge chunks' windows
         const int win = kFxChunk + 2 * pada, nstrips = fx_left_strips(pada) + g.nright;
         const size_t bytes = static_cast<size_t>(nframes) * nstrips * rows * win * 3 + 64;
@@ -1660,64 +1671,64 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
             ctx->fx_strips_bytes = bytes;
         }
     }
-    float *qrow = nullptr, *qcol = nullptr;
     const int strip_blocks = (((rows + 3) / 4) * ((kFxChunk + 2 * pada) / 4) + 255) / 256, chunks_x = (cols + kFxChunk - 1) / kFxChunk;
+    const int n_strip = strip_blocks * (fx_left_strips(pada) + g.nright) * nframes;
+    FxQuirk qk{};
     if (!p.mx_quirk) {
         TimedLaunch t(ctx, 1, nframes);
-        hipLaunchKernelGGL(fx_prepass, dim3(strip_blocks * (fx_left_strips(pada) + g.nright) * nframes), dim3(256), 0, ctx->stream, d_src, nullptr, nullptr, nullptr, ctx->fx_strips, rows, cols,
-                           p.sz.pad, pada, 1, 1, 0, chunks_x, g.nright, strip_blocks, kFxSumRows);
+        hipLaunchKernelGGL(fx_prepass, dim3(n_strip), dim3(256), 0, ctx->stream, d_src, nullptr, nullptr, nullptr, ctx->fx_strips, rows, cols, p.sz.pad, pada, 1, 1, 0, chunks_x,
+                           g.nright, strip_blocks, kFxSumRows, n_strip, nullptr, 0);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (p.mx_quirk) {
-        // scratch per frame: ints: srow_part [batches][rows][3], cpart [bands][3 cols], ccol [3 cols]; 64-bit: zpart [bands][batches][3];
-        // floats: qrow [3][qrows], qcol [qpitch]
-        const int band_rows = fx_band_rows(rows, cols), nbands = (rows + band_rows - 1) / band_rows, nbatches = (cols / 4 + 255) / 256;
-        const size_t n_srow = static_cast<size_t>(nbatches) * rows * 3, n_cpart = static_cast<size_t>(nbands) * 3 * cols, n_ccol = static_cast<size_t>(3) * cols,
-                     n_z = static_cast<size_t>(nbands) * nbatches * 3;
+        // The quirk's sums.  Two sets of accumulators {srow [frame][row][3], ccol [frame][3 cols]} (ints, added to with atomics by the
+        // pre-pass) used in turn: a call's pre-pass clears the other set for the call after it; a set this call cannot know to be
+        // clear (first use, or the geometry grew) is cleared here.  zpart [frame][band][batch][3] (64-bit) is plainly stored.
+        const int band_rows = fx_band_rows(rows, cols, nframes, ctx->num_cus), nbands = (rows + band_rows - 1) / band_rows, nbatches = (cols / 4 + 255) / 256;
         auto up4 = [](size_t v) { return (v + 3) & ~static_cast<size_t>(3); };
-        const size_t sums_bytes = (up4(n_srow * nframes) + up4(n_cpart * nframes) + up4(n_ccol * nframes)) * sizeof(int) + (n_z + 3) * nframes * sizeof(long long) + 64;
-        const size_t terms_bytes = (static_cast<size_t>(3) * qrows + qpitch) * sizeof(float) * nframes + 64;
-        if (ctx->mx_sums_bytes < sums_bytes) {
-            if (ctx->mx_sums) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->mx_sums)); ctx->mx_sums = nullptr; ctx->mx_sums_bytes = 0; }
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mx_sums), sums_bytes));
-            ctx->mx_sums_bytes = sums_bytes;
+        const size_t n_srow = up4(static_cast<size_t>(nframes) * rows * 3), n_ccol = up4(static_cast<size_t>(nframes) * 3 * cols), n_acc = n_srow + n_ccol;
+        const size_t n_z = static_cast<size_t>(nframes) * nbands * nbatches * 3;
+        if (ctx->fx_acc_ints < n_acc || ctx->fx_z_count < n_z) {
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (ctx->fx_acc) { HIP_TRY(ctx, hipFree(ctx->fx_acc)); ctx->fx_acc = nullptr; }
+            ctx->fx_acc_ints = ctx->fx_z_count = 0;
+            const size_t cap = up4(n_acc + n_acc / 8), zcap = n_z + n_z / 8 + 8;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->fx_acc), (2 * cap) * sizeof(int) + zcap * sizeof(long long)));
+            ctx->fx_acc_ints = cap;
+            ctx->fx_z_count = zcap;
+            ctx->fx_acc_clear[0] = ctx->fx_acc_clear[1] = 0;
         }
-        if (ctx->mx_terms_bytes < terms_bytes) {
-            if (ctx->mx_terms) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->mx_terms)); ctx->mx_terms = nullptr; ctx->mx_terms_bytes = 0; }
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->mx_terms), terms_bytes));
-            ctx->mx_terms_bytes = terms_bytes;
-        }
-        int* srow = ctx->mx_sums;
-        int* cpart = srow + up4(n_srow * nframes);                                      // 16-byte aligned: int4 stores
-        int* ccol = cpart + up4(n_cpart * nframes);
-        long long* zpart = reinterpret_cast<long long*>(ccol + up4(n_ccol * nframes));
-        double* zsum = reinterpret_cast<double*>(zpart + n_z * nframes);
-        qrow = ctx->mx_terms;
-        qcol = qrow + static_cast<size_t>(3) * qrows * nframes;
+        const int cur = ctx->fx_acc_phase & 1;
+        int* acc = ctx->fx_acc + static_cast<size_t>(cur) * ctx->fx_acc_ints;
+        int* other = ctx->fx_acc + static_cast<size_t>(cur ^ 1) * ctx->fx_acc_ints;
+        long long* zpart = reinterpret_cast<long long*>(ctx->fx_acc + 2 * ctx->fx_acc_ints);
+        if (ctx->fx_acc_clear[cur] < n_acc) HIP_TRY(ctx, hipMemsetAsync(acc, 0, n_acc * sizeof(int), ctx->stream));
+        int* srow = acc;
+        int* ccol = acc + n_srow;
         { TimedLaunch t(ctx, 1, nframes);
-          const int n_alt = nbands * nbatches * nframes;
-          hipLaunchKernelGGL(fx_prepass, dim3(n_alt + strip_blocks * (fx_left_strips(pada) + g.nright) * nframes), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, ctx->fx_strips, rows, cols,
-                             p.sz.pad, pada, nbands, nbatches, n_alt, chunks_x, g.nright, strip_blocks, band_rows);
-          HIP_TRY(ctx, hipGetLastError());
-          const int nrb = (qrows + 255) / 256, nvb = (3 * cols + 255) / 256, ncb = (qpitch + 255) / 256;
-          hipLaunchKernelGGL(fx_quirk_reduce, dim3(nrb + nvb + 1, nframes), dim3(256), 0, ctx->stream, srow, cpart, zpart, qrow, ccol, zsum, rows, cols, p.sz.pad, pada,
-                             qrows, nbands, nbatches, nrb, nvb, p.mxt->dr);
-          HIP_TRY(ctx, hipGetLastError());
-          const int tileints = 3 * (256 / 3 + 2 + 2 * p.sz.pad + 2);
-          const size_t lds = static_cast<size_t>(tileints) * sizeof(int) + static_cast<size_t>(2 * p.sz.pad + 1) * sizeof(float);
-          hipLaunchKernelGGL(fx_quirk_cols, dim3(ncb, nframes), dim3(256), lds, ctx->stream, ccol, zsum, p.mxt->taps_row, qcol, cols, p.sz.pad, qpitch, tileints, p.mxt->dr,
-                             p.mxt->dc);
+          const int n_alt = nbands * nbatches * nframes, zero_int4s = static_cast<int>(n_acc / 4), n_zero = (zero_int4s + 255) / 256;
+          hipLaunchKernelGGL(fx_prepass, dim3(n_alt + n_strip + n_zero), dim3(256), 0, ctx->stream, d_src, srow, ccol, zpart, ctx->fx_strips, rows, cols, p.sz.pad, pada, nbands,
+                             nbatches, n_alt, chunks_x, g.nright, strip_blocks, band_rows, n_strip, reinterpret_cast<int4*>(other), zero_int4s);
           HIP_TRY(ctx, hipGetLastError()); }
+        ctx->fx_acc_clear[cur] = 0;
+        ctx->fx_acc_clear[cur ^ 1] = n_acc;
+        ctx->fx_acc_phase ^= 1;
+        qk.srow = srow;
+        qk.ccol = ccol;
+        qk.zpart = zpart;
+        qk.taps = p.mxt->taps_row;
+        qk.nz = nbands * nbatches;
+        qk.dr = p.mxt->dr;
+        qk.dc = p.mxt->dc;
     }
     // diagnostic (timing-only -DFX_STAMPS builds of the kernel write here; see tools/fx_variants.sh): cycles per phase kind
     unsigned long long* stamps = nullptr;
-    if (!p.mx_quirk && std::getenv("BLUR_FX_STAMPS")) {
+    if (!p.mx_quirk && !vdump && std::getenv("BLUR_FX_STAMPS")) {
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&stamps), 64));
         HIP_TRY(ctx, hipMemset(stamps, 0, 64));
-        qcol = reinterpret_cast<float*>(stamps);
     }
     { TimedLaunch t(ctx, 0, nframes);
-      HIP_TRY(ctx, p.fx->blur_u8(ctx->stream, d_src, d_dst, p.mxt->frags_row, g, ctx->num_cus, qrow, qcol, qpitch, ctx->fx_strips, vdump)); }
+      HIP_TRY(ctx, p.fx->blur_u8(ctx->stream, d_src, d_dst, p.mxt->frags_row, g, ctx->num_cus, p.mx_quirk ? &qk : nullptr, ctx->fx_strips, vdump, stamps)); }
     if (stamps) {
         unsigned long long h[8];
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

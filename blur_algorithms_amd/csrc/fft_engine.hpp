@@ -29,6 +29,7 @@ struct DevPlan {
     int radix[kMaxPassesDev];
     int m[kMaxPassesDev];
     int tw_off[kMaxPassesDev];
+    int nxcd;                       // XCDs of the device the launch goes to (0: unknown -> 8); filled in at the launch
 };
 
 BLUR_HD float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }

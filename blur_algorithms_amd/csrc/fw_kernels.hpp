@@ -35,8 +35,7 @@ template <int NKB> struct FwCfg {
 
 template <int NKB, bool QUIRK>
 __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, FxGeom g,
-                                                     int chunks, int tps, int nseg, int ntasks, const float* __restrict__ qrow, const float* __restrict__ qcol,
-                                                     int qpitch, const uint8_t* __restrict__ strips)
+                                                     int chunks, int tps, int nseg, int ntasks, FxQuirk qk, const uint8_t* __restrict__ strips)
 {
     using C = FwCfg<NKB>;
     constexpr int PADA = C::PADA, PW = C::PW, NT = C::NT, PER = C::PER;
@@ -67,15 +66,19 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
     const mx_half8* tlp = reinterpret_cast<const mx_half8*>(fw_lds + C::TLOFF) + lane;
     auto tlo = [&](int kb) __attribute__((always_inline)) { return kb < TLR ? tlr[kb < TLR ? kb : 0] : tlp[kb * 64]; };
 
-    float cpos, cneg;
-    {
-        const int x = x0 + 32 * wave + m;
-        float qc = 0.f;
-        if (QUIRK && x < g.cols) qc = qcol[static_cast<size_t>(f) * qpitch + 3 * x + c];
-        cpos = 0.5f + qc;
-        cneg = 0.5f - qc;
+    float cpos = 0.5f, cneg = 0.5f;
+    if (QUIRK) {
+        // the column term of this chunk's pixels in the task's channel (fx_kernels.hpp: fx_quirk_cols_tile; the window buffers are
+        // not in use yet: tile and taps in buffer 0, the result in buffer 1)
+        float* qc = reinterpret_cast<float*>(fw_lds + C::BUF);
+        fx_quirk_cols_tile<1>(fw_lds, qc, qk, f, x0, c, g.cols, g.pad, tid);
+        const float v = qc[32 * wave + m];
+        cpos = 0.5f + v;
+        cneg = 0.5f - v;
+        __syncthreads();                                   // before the staging writes windows over it
     }
     const int qrows = 32 * (g.ntiles + NT);
+    const double qrs = QUIRK ? static_cast<double>(qk.dr) * ((g.pad & 1) ? -1.0 : 1.0) : 0.0;
 
     const mx_float16 zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     mx_float16 acc[NT];
@@ -111,7 +114,8 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
             const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rimg, in ? off + 96u * k : off, 0, 0);
             raw[k][0] = t[0]; raw[k][1] = t[1]; raw[k][2] = t[2];
         }
-        if (QUIRK && tid < 32) qraw = qrow[(static_cast<size_t>(f) * 3 + c) * qrows + min(32 * s + tid, qrows - 1)];
+        if (QUIRK && tid < 32)          // the row term of row re of V (= image row refl(re - PADA)): dr (-1)^pad Srow
+            qraw = static_cast<float>(qrs * qk.srow[(static_cast<size_t>(f) * g.rows + mx_refl(min(32 * s + tid, qrows - 1) - PADA, g.rows)) * 3 + c]);
     };
     // channel c of group k -> binary16 subnormals -> LDS: two v_perm_b32 (run-time selectors: the channel is the task's) and one
     // ds_write_b64.  Pixels (0, 1) of the group are bytes (c, 3 + c), pixels (2, 3) bytes (6 + c, 9 + c) of its three dwords.
@@ -324,11 +328,11 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
     }
 }
 
-template <int NKB> hipError_t fw_launch_u8(hipStream_t st, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const float* qrow,
-                                           const float* qcol, int qpitch, const uint8_t* strips, float* vdump)
+template <int NKB> hipError_t fw_launch_u8(hipStream_t st, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const FxQuirk* qk,
+                                           const uint8_t* strips, float* vdump, unsigned long long* stamps)
 {
     using C = FwCfg<NKB>;
-    if (vdump) return hipErrorNotSupported;                      // the row-pass dump is a test build of fx_blur_u8 only
+    if (vdump || stamps) return hipErrorNotSupported;            // the row-pass dump and the phase stamps are builds of fx_blur_u8 only
     const int chunks = (g.cols + kFxChunk - 1) / kFxChunk;
     const long long nstripes = static_cast<long long>(chunks) * g.nframes * 3;      // (strip of columns, channel)
     if (nstripes <= 0) return hipSuccess;
@@ -346,21 +350,22 @@ template <int NKB> hipError_t fw_launch_u8(hipStream_t st, const uint8_t* src, u
     if (g.nxcd < 1) g.nxcd = 1;
     const int per_xcd = static_cast<int>((ntasks + g.nxcd - 1) / g.nxcd);
     const dim3 grid(static_cast<unsigned>(g.nxcd * per_xcd));
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned long long> attr_done{ 0 };
+    int dev;
+    if (fx_attr_needed(attr_done, dev)) {
         const void* kernels[2] = { reinterpret_cast<const void*>(fw_blur_u8<NKB, true>), reinterpret_cast<const void*>(fw_blur_u8<NKB, false>) };
         for (const void* k : kernels) {
             const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
             if (e != hipSuccess) return e;
         }
-        attr_done = true;
+        fx_attr_mark(attr_done, dev);
     }
-    if (qrow)
+    if (qk)
         hipLaunchKernelGGL((fw_blur_u8<NKB, true>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg,
-                           static_cast<int>(ntasks), qrow, qcol, qpitch, strips);
+                           static_cast<int>(ntasks), *qk, strips);
     else
         hipLaunchKernelGGL((fw_blur_u8<NKB, false>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg,
-                           static_cast<int>(ntasks), qrow, qcol, qpitch, strips);
+                           static_cast<int>(ntasks), FxQuirk{}, strips);
     return hipGetLastError();
 }
 

@@ -24,11 +24,12 @@
 // + 3 B/px written.  The kernel is bound by the matrix pipe: 55 MFMAs per (32 x 32 tile, channel) for NKB = 11.
 //
 // The Nyquist-slot quirk of pffft_() (Source.cpp:420-425; notes in mx_kernels.hpp) needs the alternating sums of whole image
-// rows and columns BEFORE a pixel can leave, so they come from a pre-pass over the image (fx_altsums: exact integers) and two
-// small kernels that turn them into the per-row and per-column terms qrow / qcol; the column sums of V the column term is
-// made of are, by linearity, the row convolution of the image's weighted column sums.
+// rows and columns BEFORE a pixel can leave, so they come from a pre-pass over the image (fx_prepass: exact integers, complete
+// when it ends), and the fused kernel turns them into its per-row and per-column terms itself (struct FxQuirk); the column sums
+// of V the column term is made of are, by linearity, the row convolution of the image's weighted column sums.
 #pragma once
 #include "mx_kernels.hpp"
+#include <atomic>
 
 #if !defined(FX_NO_SGB) && !defined(FX_SGB)
 #define FX_SGB 1     // ask the scheduler for the interleaved order of each phase (sched_group_barrier)
@@ -96,9 +97,71 @@ __device__ __forceinline__ uint32_t fx_quad_transpose(uint32_t p, uint32_t sel1,
     return __builtin_amdgcn_perm(u, q, sel2);
 }
 
+// What the fused kernels need for the Nyquist-slot quirk (Source.cpp:420-425; the algebra is at fx_altsums_body): the pre-pass's
+// exact integer sums, complete when the fused kernel starts, and the taps.  The kernels turn them into their terms themselves:
+//   row term      qrow(r, c) = dr (-1)^pad Srow(r, c), added to V as qrow (-1)^x                    (one load + three conversions per row)
+//   column term   qcol(x, c) = dc (-1)^pad (rowconv(Ccol)(x, c) + dr (-1)^(x+pad) Z(c)), added to the output as qcol (-1)^r: a
+//                 workgroup convolves the 128 + 2 pad values of Ccol around its own chunk in its prologue (fx_quirk_cols_tile)
+// so a call is two launches (pre-pass, fused kernel); rounds 2-3 had two more kernels for the terms between them.
+struct FxQuirk {
+    const int* srow;            // [frame][row][3]      Srow(r, c) = sum_x wx(x) img[r][x][c]
+    const int* ccol;            // [frame][3 x + c]     Ccol(x, c) = sum_r wy(r) img[r][x][c]
+    const long long* zpart;     // [frame][nz][3]       parts of Z(c) = sum_r wy(r) Srow(r, c)
+    const float* taps;          // the 2 pad + 1 taps of the row pass, centre at pad
+    int nz;
+    float dr, dc;
+};
+
+// qc[NCH xl + c] (xl = 0 .. 127; NCH = 3: c = 0 .. 2, NCH = 1: channel c0 only) = the column term of pixel x0 + xl, 0 right of the
+// image.  256 threads; `scratch` = LDS for NCH (128 + 2 pad) ints + (2 pad + 1) floats + 4 doubles; ends with a barrier, after which
+// scratch is free again and qc is valid.  The convolution runs in double over the LDS tile (reflect-101 applied when it is filled).
+template <int NCH>
+__device__ __forceinline__ void fx_quirk_cols_tile(unsigned char* scratch, float* qc, const FxQuirk& q, int f, int x0, int c0, int cols, int pad, int tid)
+{
+    const int win = kFxChunk + 2 * pad, nval = NCH * win, ntap = 2 * pad + 1;
+    int* cc = reinterpret_cast<int*>(scratch);
+    float* tp = reinterpret_cast<float*>(cc + nval);
+    double* zs = reinterpret_cast<double*>(scratch + ((static_cast<size_t>(nval + ntap) * 4 + 7) & ~static_cast<size_t>(7)));
+    for (int i = tid; i < nval; i += 256) {
+        const int p = i / NCH, ch = NCH == 3 ? i - 3 * p : c0;
+        cc[i] = q.ccol[static_cast<size_t>(f) * 3 * cols + 3 * mx_refl(x0 - pad + p, cols) + ch];
+    }
+    for (int i = tid; i < ntap; i += 256) tp[i] = q.taps[i];
+    {   // Z: wave w < 3 adds up channel w's parts (exact integers), a lane per part, then across the wave
+        const int w = tid >> 6, l = tid & 63;
+        if (w < 3 && (NCH == 3 || w == c0)) {
+            long long z = 0;
+            for (int i = l; i < q.nz; i += 64) z += q.zpart[(static_cast<size_t>(f) * q.nz + i) * 3 + w];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) z += __shfl_xor(z, o, 64);
+            if (l == 0) zs[w] = static_cast<double>(z);
+        }
+    }
+    __syncthreads();
+    const double sp = (pad & 1) ? -1.0 : 1.0;
+    for (int e = tid; e < NCH * kFxChunk; e += 256) {
+        const int xl = e / NCH, c = NCH == 3 ? e - 3 * xl : c0, x = x0 + xl;
+        float out = 0.f;
+        if (x < cols) {
+            const int* ccx = cc + NCH * xl + (NCH == 3 ? c : 0);              // tap t = -pad sits here
+            double acc[4] = { 0, 0, 0, 0 };
+            int t = 0;
+            for (; t + 4 <= ntap; t += 4) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += static_cast<double>(tp[t + j]) * ccx[NCH * (t + j)];
+            }
+            for (; t < ntap; ++t) acc[0] += static_cast<double>(tp[t]) * ccx[NCH * t];
+            const double sx = ((x + pad) & 1) ? -1.0 : 1.0;
+            out = static_cast<float>(static_cast<double>(q.dc) * sp * (((acc[0] + acc[1]) + (acc[2] + acc[3])) + static_cast<double>(q.dr) * sx * zs[c]));
+        }
+        qc[e] = out;
+    }
+    __syncthreads();
+}
+
 // One workgroup per (frame, segment of output tiles, chunk of 128 pixel columns).
-//   qrow[f][c][re]   the row pass's quirk term per row of V (re = image row + PADA, mirrored rows included), added as qrow * (-1)^x
-//   qcol[f][3 x + c] the column pass's quirk term, added as qcol * (-1)^r
+//   qk (QUIRK)       the pre-pass's integer sums: the row pass's term qrow (-1)^x per row of V and the column pass's term qcol (-1)^r
+//                    per output column are made from them here (struct FxQuirk)
 //
 // Software pipeline.  n = (step s, channel c) enumerates the wave's (32 rows x 32 pixels) products; per n the matrix pipe runs
 //     phase A(n):  R(n+1)  row pass of the NEXT product (2 NKB MFMAs)            beside: staging of later windows, the stores
@@ -111,8 +174,8 @@ __device__ __forceinline__ uint32_t fx_quad_transpose(uint32_t p, uint32_t sel1,
 // hand-off reads them, also go to vdump[frame][channel][row][col] -- what the reference holds in `resf` after Source.cpp:520-537.
 template <int NKB, bool QUIRK, bool DUMPV = false>
 __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, FxGeom g,
-                                                     int chunks, int tps, int nseg, int ntasks, const float* __restrict__ qrow, const float* __restrict__ qcol,
-                                                     int qpitch, const uint8_t* __restrict__ strips, float* __restrict__ vdump)
+                                                     int chunks, int tps, int nseg, int ntasks, FxQuirk qk, const uint8_t* __restrict__ strips,
+                                                     float* __restrict__ vdump)
 {
     using C = FxCfg<NKB>;
     constexpr int PADA = C::PADA, PW = C::PW, NT = C::NT, PER = C::PER;
@@ -146,17 +209,23 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     const int xpix = x0 + 32 * wave + 4 * Q;                       // first of the lane's 4 pixels after the transposes
     const bool in_cols = xpix < g.cols;
     float cpos[3], cneg[3];
-    {
-        const int x = x0 + 32 * wave + m;
+    if (QUIRK) {
+        // the column term of this chunk's pixels (nothing else uses LDS yet: tile and taps in window buffer 0, the result in buffer 1)
+        float* qc = reinterpret_cast<float*>(fx_lds + C::BUF);
+        fx_quirk_cols_tile<3>(fx_lds, qc, qk, f, x0, 0, g.cols, g.pad, tid);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float qc = 0.f;
-            if (QUIRK && x < g.cols) qc = qcol[static_cast<size_t>(f) * qpitch + 3 * x + c];
-            cpos[c] = 0.5f + qc;
-            cneg[c] = 0.5f - qc;
+            const float v = qc[3 * (32 * wave + m) + c];
+            cpos[c] = 0.5f + v;
+            cneg[c] = 0.5f - v;
         }
+        __syncthreads();                                   // before the staging writes windows over it
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cpos[c] = cneg[c] = 0.5f;
     }
     const int qrows = 32 * (g.ntiles + NT);
+    const double qrs = QUIRK ? static_cast<double>(qk.dr) * ((g.pad & 1) ? -1.0 : 1.0) : 0.0;
 
     const mx_float16 zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
     mx_float16 acc[3][NT];
@@ -184,8 +253,16 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     const uint8_t* wbase = sidx >= 0 ? strips + (static_cast<size_t>(f) * (NLEFT + g.nright) + sidx) * g.rows * (3 * C::WIN) : img + 3 * (x0 - PADA);
     const uint32_t wbytes = sidx >= 0 ? static_cast<uint32_t>(g.rows) * 3u * C::WIN : (static_cast<uint32_t>(g.rows) * g.cols - static_cast<uint32_t>(x0 - PADA)) * 3u;
     const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wbase), 0, wbytes, kMxRsrcWord3);
+    // staging map: a thread owns the 12-byte groups g0 + 8 k of window row `srow`.  ds_write_b64 is served in groups of 16 lanes over 32
+    // banks: the two rows of a group must lie 16 banks apart, and the row pitch is 4 mod 8 dwords, so they are rows a and a + 4
+    // (a wave still covers 8 consecutive rows: its loads are 8 rows x 96 contiguous bytes as before)
+#ifdef FX_STAGE_LINEAR
+    const int srow = tid >> 3;
+#else
+    const int srow = 8 * (tid >> 6) + ((tid >> 4) & 3) + 4 * ((tid >> 3) & 1);
+#endif
     auto issue_chunk = [&](int s, int j) __attribute__((always_inline)) {
-        const int row = tid >> 3, g0 = tid & 7;
+        const int row = srow, g0 = tid & 7;
 #ifdef FX_ABL_NOLOAD
         if (s >= 0) return;
 #endif
@@ -199,8 +276,9 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
             raw.d[k][0] = t[0]; raw.d[k][1] = t[1]; raw.d[k][2] = t[2];
         }
         if (QUIRK && j == 0 && tid < 96) {
-            const int c = tid >> 5, re = 32 * s + (tid & 31);
-            qraw = qrow[(static_cast<size_t>(f) * 3 + c) * qrows + min(re, qrows - 1)];
+            // the row term of row re of V (= image row refl(re - PADA)): dr (-1)^pad Srow, rounded once as the term kernels of rounds 2-3 did
+            const int c = tid >> 5, re = min(32 * s + (tid & 31), qrows - 1);
+            qraw = static_cast<float>(qrs * qk.srow[(static_cast<size_t>(f) * g.rows + mx_refl(re - PADA, g.rows)) * 3 + c]);
         }
     };
     // one (group k, channel c) of the window: two v_perm_b32 (deinterleave + the low byte of a binary16 each) and one ds_write_b64
@@ -208,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #ifdef FX_ABL_NOCOMMIT
         if (buf >= 0) return;
 #endif
-        const int row = tid >> 3, g0 = tid & 7;
+        const int row = srow, g0 = tid & 7;
         if (k >= PER) return;
         if ((C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8) {
             _Float16* base = reinterpret_cast<_Float16*>(fx_lds + buf * C::BUF) + row * PW + 4 * g0;
@@ -444,7 +522,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     split_piece(0, 0, 4, s0);
 
 #ifdef FX_STAMPS
-    // timing-only build: cycles (s_memtime) per phase kind, summed over the steps, by wave 0 of workgroup 0 -> the buffer passed as qcol
+    // timing-only build: cycles (s_memtime) per phase kind, summed over the steps, by wave 0 of workgroup 0 -> the buffer passed as vdump
     unsigned long long st_acc[6] = { 0, 0, 0, 0, 0, 0 }, st_prev = __builtin_amdgcn_s_memtime(), st_begin = st_prev;
 #define FX_STAMP(i) { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); st_acc[i] += t_ - st_prev; st_prev = t_; }
 #else
@@ -528,8 +606,8 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     }
     store_tile(s1 - 1 - NT, s1 - 1 - NT >= tile0);
 #ifdef FX_STAMPS
-    if (!QUIRK && qcol && blockIdx.x == 0 && tid == 0) {
-        unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(qcol));
+    if (!QUIRK && !DUMPV && vdump && blockIdx.x == 0 && tid == 0) {        // (timing-only build: vdump carries the stamp buffer)
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(vdump);
         for (int i = 0; i < 6; ++i) o[i] = st_acc[i];
         o[6] = __builtin_amdgcn_s_memtime() - st_begin;
         o[7] = static_cast<unsigned long long>(s1 - s0);
@@ -544,9 +622,9 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 //     out[r][x] = colconv(V')[r][x] + dc (-1)^(r+pad) Scol(x),  Scol(x) = sum_r wy(r) V'[r][x]
 //                                                                       = rowconv(Ccol)(x) + dr (-1)^(x+pad) Z
 //     Ccol(x) = sum_r wy(r) img[r][x]  (integers; the row convolution and the weighted column sum commute),  Z = sum_r wy(r) Srow(r)
-// fx_altsums reads the image once and leaves the parts of Srow, Ccol and Z; fx_quirk_reduce and fx_quirk_cols turn them into
-// qrow[f][c][re] = dr (-1)^pad Srow[refl(re - PADA)][c] and qcol[f][3 x + c] = dc (-1)^pad Scol, which the fused kernel adds
-// as qrow (-1)^x (to V, before the hand-off) and qcol (-1)^r (to the output, before the truncation).
+// fx_prepass reads the image once and leaves Srow, Ccol (whole, by integer atomics) and the parts of Z; the fused kernel adds
+// qrow (-1)^x = dr (-1)^pad Srow[refl(re - PADA)][c] (-1)^x to V before the hand-off and qcol (-1)^r = dc (-1)^pad Scol (-1)^r to the
+// output before the truncation (struct FxQuirk, fx_quirk_cols_tile).
 #ifdef BLUR_FX_QUIRK_KERNELS   // engine.hip only: plain (non-template) kernels must live in one translation unit
 // chunks at the right edge whose window (128 + 2 pada columns from 128 xc - pada) reaches past the image: they read a strip
 inline int fx_right_strips(int cols, int pada)
@@ -611,28 +689,29 @@ __device__ __forceinline__ void fx_edge_strips_body(const uint8_t* __restrict__ 
     }
 }
 
-constexpr int kFxSumRows = 32;          // most image rows per band (packed 16-bit column sums: 32 x 3 x 255 < 65536); small frames take 16:
-                                        // twice the workgroups, each half as long (fx_band_rows)
-inline int fx_band_rows(int rows, int cols) { return static_cast<long long>(rows) * cols < 4000000ll ? 16 : kFxSumRows; }
-
-// sum over the 16 lanes of a DPP row, valid in every lane of the row
-__device__ __forceinline__ int fx_row16_sum(int v)
+constexpr int kFxSumRows = 32;          // image rows per sub-band (packed 16-bit column sums: 32 x 3 x 255 < 65536)
+// rows per workgroup of the pre-pass: sub-bands of 32 (16 for small frames: twice the workgroups, each half as long).  Every band adds
+// its column sums to Ccol with atomics (12 wave-instructions per wave), so tall bands where the batch still gives four workgroups per CU
+inline int fx_band_rows(int rows, int cols, int nframes, int num_cus)
 {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xb1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4e, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true);    // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, true);    // row_mirror
-    return v;
+    if (static_cast<long long>(rows) * cols < 4000000ll) return 16;
+    const long long nbatches = (cols / 4 + 255) / 256;
+    int br = kFxSumRows;
+    while (br < 128 && nbatches * ((rows + 2 * br - 1) / (2 * br)) * nframes >= 4ll * num_cus) br *= 2;
+    return br;
 }
 
-// grid (bands of kFxSumRows rows, batches of 256 twelve-byte groups = 1024 pixel columns, frames), 256 threads: a thread owns one
-// group (4 pixels) of every row of the band, eight rows of loads in flight; cols % 4 == 0, frames 4-byte aligned.
-//   srow_part[f][batch][r][c]  sum over the batch's pixels of wx(x) img[r][x][c]
-//   cpart[f][band][3 x + c]    sum over the band's rows of wy(r) img[r][x][c]
-//   zpart[f][band][batch][c]   sum over the band's rows of wy(r) srow_part[f][batch][r][c]       (the parts of Z)
+// workgroup (band of band_rows rows, batch of 256 twelve-byte groups = 1024 pixel columns, frame), 256 threads: a thread owns one
+// group (4 pixels) of every row of the band, eight rows of loads in flight; cols % 4 == 0, frames 4-byte aligned.  Exact integers:
+//   srow[f][r][c]            += sum over the batch's pixels of wx(x) img[r][x][c]        (atomics: the batches of a row)
+//   ccol[f][3 x + c]         += sum over the band's rows of wy(r) img[r][x][c]           (atomics: the bands of a column; a wave
+//                                                                                         instruction adds 256 contiguous bytes)
+//   zpart[f][band][batch][c]  = sum over the band's rows of wy(r) x (the batch's part of Srow(r, c))     (plain stores)
+// so Srow and Ccol are complete when the launch ends and nothing has to be reduced between it and the fused kernel.  (Integer
+// atomics: the result does not depend on the order.  They execute at the memory side, device scope: the XCDs' L2s are not coherent.)
 // sred[row][channel][lane]: lane l of every wave adds into slot l (one conflict-free ds_add_u32 per value: a same-address atomic the
 // compiler would turn into a serial loop over the lanes, and a DPP reduction costs twelve dependent instructions)
-__device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
+__device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src, int* __restrict__ srow, int* __restrict__ ccol, long long* __restrict__ zpart,
                                                 int rows, int cols, int pad, int nbands, int nbatches, int band, int batch, int f, int (*sred)[3][64], int band_rows)
 {
     const int tid = threadIdx.x;
@@ -640,213 +719,162 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
     const int groups = cols / 4, r0 = band * band_rows, r1 = min(r0 + band_rows, rows);
     const int gi = batch * 256 + tid, x = 4 * gi;
     const bool act = gi < groups;
-    for (int i = tid; i < band_rows * 3 * 64; i += 256) (&sred[0][0][0])[i] = 0;
-    __syncthreads();
     const int flip = (pad & 1) ? -1 : 1;
     const bool plain = x > pad && x + 3 < cols - 1 - pad;                 // no pixel of the group is mirrored: weights +-1 by parity
     int wq[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) wq[q] = act ? mx_alt_weight(x + q, cols, pad) : 0;
-    uint32_t accp[6], accn[6];                                            // packed 16-bit sums of the rows with positive / negative wy
+    int o[12];                                                            // the band's column sums of the thread's 12 bytes
 #pragma unroll
-    for (int j = 0; j < 6; ++j) accp[j] = accn[j] = 0;
+    for (int j = 0; j < 12; ++j) o[j] = 0;
+    long long zacc = 0;                                                   // threads 0 .. 95 = (row of the sub-band, channel)
     typedef uint32_t u3 __attribute__((ext_vector_type(3)));
     const uint8_t* col0 = img + 12 * static_cast<size_t>(act ? gi : 0);
-    for (int rb = r0; rb < r1; rb += 8) {
-        u3 d[8];
+    for (int rs = r0; rs < r1; rs += kFxSumRows) {
+        const int re = min(rs + kFxSumRows, r1);
+        for (int i = tid; i < kFxSumRows * 3 * 64; i += 256) (&sred[0][0][0])[i] = 0;
+        __syncthreads();
+        uint32_t accp[6], accn[6];                                        // packed 16-bit sums of the rows with positive / negative wy
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = min(rb + i, r1 - 1);
-            d[i] = *reinterpret_cast<const u3*>(col0 + static_cast<size_t>(r) * cols * 3);
-        }
+        for (int j = 0; j < 6; ++j) accp[j] = accn[j] = 0;
+        for (int rb = rs; rb < re; rb += 8) {
+            u3 d[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = rb + i;
-            if (r < r1) {                                                    // uniform
-                const int wy = mx_alt_weight(r, rows, pad);
-                int s[3] = { 0, 0, 0 };
-                if (plain) {
-                    const int e0 = static_cast<int>(d[i][0] ^ 0x80808080u), e1 = static_cast<int>(d[i][1] ^ 0x80808080u), e2 = static_cast<int>(d[i][2] ^ 0x80808080u);
-                    // bytes (pixel q, channel c) = 3 q + c of the group, signs + - + - over q; the offset 128 cancels (weights sum to 0)
-                    int t0 = __builtin_amdgcn_sdot4(e0, static_cast<int>(0xff000001u), 0, false);
-                    t0 = __builtin_amdgcn_sdot4(e1, 0x00010000, t0, false);
-                    t0 = __builtin_amdgcn_sdot4(e2, 0x0000ff00, t0, false);
-                    int t1 = __builtin_amdgcn_sdot4(e0, 0x00000100, 0, false);
-                    t1 = __builtin_amdgcn_sdot4(e1, 0x010000ff, t1, false);
-                    t1 = __builtin_amdgcn_sdot4(e2, 0x00ff0000, t1, false);
-                    int t2 = __builtin_amdgcn_sdot4(e0, 0x00010000, 0, false);
-                    t2 = __builtin_amdgcn_sdot4(e1, 0x0000ff00, t2, false);
-                    t2 = __builtin_amdgcn_sdot4(e2, static_cast<int>(0xff000001u), t2, false);
-                    s[0] = flip * t0; s[1] = flip * t1; s[2] = flip * t2;
-                } else {
+            for (int i = 0; i < 8; ++i) {
+                const int r = min(rb + i, re - 1);
+                d[i] = *reinterpret_cast<const u3*>(col0 + static_cast<size_t>(r) * cols * 3);
+            }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
+            for (int i = 0; i < 8; ++i) {
+                const int r = rb + i;
+                if (r < re) {                                                    // uniform
+                    const int wy = mx_alt_weight(r, rows, pad);
+                    int s[3] = { 0, 0, 0 };
+                    if (plain) {
+                        const int e0 = static_cast<int>(d[i][0] ^ 0x80808080u), e1 = static_cast<int>(d[i][1] ^ 0x80808080u), e2 = static_cast<int>(d[i][2] ^ 0x80808080u);
+                        // bytes (pixel q, channel c) = 3 q + c of the group, signs + - + - over q; the offset 128 cancels (weights sum to 0)
+                        int t0 = __builtin_amdgcn_sdot4(e0, static_cast<int>(0xff000001u), 0, false);
+                        t0 = __builtin_amdgcn_sdot4(e1, 0x00010000, t0, false);
+                        t0 = __builtin_amdgcn_sdot4(e2, 0x0000ff00, t0, false);
+                        int t1 = __builtin_amdgcn_sdot4(e0, 0x00000100, 0, false);
+                        t1 = __builtin_amdgcn_sdot4(e1, 0x010000ff, t1, false);
+                        t1 = __builtin_amdgcn_sdot4(e2, 0x00ff0000, t1, false);
+                        int t2 = __builtin_amdgcn_sdot4(e0, 0x00010000, 0, false);
+                        t2 = __builtin_amdgcn_sdot4(e1, 0x0000ff00, t2, false);
+                        t2 = __builtin_amdgcn_sdot4(e2, static_cast<int>(0xff000001u), t2, false);
+                        s[0] = flip * t0; s[1] = flip * t1; s[2] = flip * t2;
+                    } else {
 #pragma unroll
-                        for (int c = 0; c < 3; ++c) {
-                            const int byte = 3 * q + c;
-                            s[c] += wq[q] * static_cast<int>((d[i][byte >> 2] >> (8 * (byte & 3))) & 0xffu);
-                        }
-                }
+                        for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int c = 0; c < 3; ++c) atomicAdd(&sred[r - r0][c][tid & 63], act ? s[c] : 0);
-                // column sums: bytes 0, 2 of each dword in one packed pair, bytes 1, 3 in the other; |wy| = 1, 2 or 3 (uniform)
-                const uint32_t aw = static_cast<uint32_t>(wy < 0 ? -wy : wy);
+                            for (int c = 0; c < 3; ++c) {
+                                const int byte = 3 * q + c;
+                                s[c] += wq[q] * static_cast<int>((d[i][byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+                            }
+                    }
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    uint32_t lo = __builtin_amdgcn_perm(0u, d[i][j], 0x0c020c00u), hi = __builtin_amdgcn_perm(0u, d[i][j], 0x0c030c01u);     // bytes 0, 2 | 1, 3
-                    if (aw != 1) { lo *= aw; hi *= aw; }                      // (uniform: the mirrored rows only)
-                    if (wy > 0) { accp[2 * j] += lo; accp[2 * j + 1] += hi; }
-                    else { accn[2 * j] += lo; accn[2 * j + 1] += hi; }
+                    for (int c = 0; c < 3; ++c) atomicAdd(&sred[r - rs][c][tid & 63], act ? s[c] : 0);
+                    // column sums: bytes 0, 2 of each dword in one packed pair, bytes 1, 3 in the other; |wy| = 1, 2 or 3 (uniform)
+                    const uint32_t aw = static_cast<uint32_t>(wy < 0 ? -wy : wy);
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        uint32_t lo = __builtin_amdgcn_perm(0u, d[i][j], 0x0c020c00u), hi = __builtin_amdgcn_perm(0u, d[i][j], 0x0c030c01u);     // bytes 0, 2 | 1, 3
+                        if (aw != 1) { lo *= aw; hi *= aw; }                      // (uniform: the mirrored rows only)
+                        if (wy > 0) { accp[2 * j] += lo; accp[2 * j + 1] += hi; }
+                        else { accn[2 * j] += lo; accn[2 * j + 1] += hi; }
+                    }
                 }
             }
         }
-    }
-    if (act) {
-        int o[12];
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            o[4 * j] = static_cast<int>(accp[2 * j] & 0xffffu) - static_cast<int>(accn[2 * j] & 0xffffu);
-            o[4 * j + 2] = static_cast<int>(accp[2 * j] >> 16) - static_cast<int>(accn[2 * j] >> 16);
-            o[4 * j + 1] = static_cast<int>(accp[2 * j + 1] & 0xffffu) - static_cast<int>(accn[2 * j + 1] & 0xffffu);
-            o[4 * j + 3] = static_cast<int>(accp[2 * j + 1] >> 16) - static_cast<int>(accn[2 * j + 1] >> 16);
+            o[4 * j] += static_cast<int>(accp[2 * j] & 0xffffu) - static_cast<int>(accn[2 * j] & 0xffffu);
+            o[4 * j + 2] += static_cast<int>(accp[2 * j] >> 16) - static_cast<int>(accn[2 * j] >> 16);
+            o[4 * j + 1] += static_cast<int>(accp[2 * j + 1] & 0xffffu) - static_cast<int>(accn[2 * j + 1] & 0xffffu);
+            o[4 * j + 3] += static_cast<int>(accp[2 * j + 1] >> 16) - static_cast<int>(accn[2 * j + 1] >> 16);
         }
-        int4* dstp = reinterpret_cast<int4*>(cpart + (static_cast<size_t>(f) * nbands + band) * (3 * cols) + 12 * gi);
-        dstp[0] = make_int4(o[0], o[1], o[2], o[3]);
-        dstp[1] = make_int4(o[4], o[5], o[6], o[7]);
-        dstp[2] = make_int4(o[8], o[9], o[10], o[11]);
-    }
-    __syncthreads();
-    if (tid < (r1 - r0) * 3) {
-        const int* p64 = &sred[0][0][0] + 64 * tid;
-        int v = 0;
+        __syncthreads();
+        if (tid < (re - rs) * 3) {
+            const int* p64 = &sred[0][0][0] + 64 * tid;
+            int v = 0;
 #pragma unroll
-        for (int k = 0; k < 64; ++k) v += p64[(k + tid) & 63];              // (rotated: the 96 threads start on different banks)
-        srow_part[((static_cast<size_t>(f) * nbatches + batch) * rows + r0) * 3 + tid] = v;
-        (&sred[0][0][0])[64 * tid] = v;                    // (slot 0 of its own 64: nobody else reads or writes it any more)
+            for (int k = 0; k < 64; ++k) v += p64[(k + tid) & 63];              // (rotated: the 96 threads start on different banks)
+            atomicAdd(&srow[(static_cast<size_t>(f) * rows + rs) * 3 + tid], v);
+            zacc += static_cast<long long>(mx_alt_weight(rs + tid / 3, rows, pad)) * v;
+        }
+        __syncthreads();                                                   // sred is zeroed again / reused below
     }
+    // the column sums: through LDS so that a wave's atomic instruction covers 64 consecutive ints (a lane's own 12 lie 48 bytes
+    // from its neighbour's: scattered atomics run at a fraction of the rate); then Z's part of this workgroup
+    int* ex = &sred[0][0][0];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) ex[12 * tid + j] = o[j];
+    long long* zs = reinterpret_cast<long long*>(ex + 12 * 256);
+    if (tid < 96) zs[tid] = zacc;
     __syncthreads();
+    {
+        const int first = 12 * 256 * batch, lim = 3 * cols - first;        // ints of this batch inside the row of 3 cols
+        int* cdst = ccol + static_cast<size_t>(f) * 3 * cols + first;
+#pragma unroll
+        for (int j = 0; j < 12; ++j) {
+            const int idx = 256 * j + tid;
+            if (idx < lim) atomicAdd(&cdst[idx], ex[idx]);
+        }
+    }
     if (tid < 3) {
         long long z = 0;
-        for (int r = r0; r < r1; ++r) z += static_cast<long long>(mx_alt_weight(r, rows, pad)) * sred[r - r0][tid][0];
+        for (int k = 0; k < kFxSumRows; ++k) z += zs[3 * k + tid];
         zpart[((static_cast<size_t>(f) * nbands + band) * nbatches + batch) * 3 + tid] = z;
     }
 }
 
 // One launch for everything that has to happen before the fused kernel: the quirk's sums (n_alt = bands x batches x frames workgroups,
-// none with nyquist_quirk = 0) and the edge strips (strip_blocks x nstrips x frames workgroups, last in the grid: they fill the tail)
-__global__ __launch_bounds__(256) void fx_prepass(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
+// none with nyquist_quirk = 0), the edge strips (strip_blocks x nstrips x frames workgroups), and last in the grid n_zero workgroups that
+// clear the OTHER set of accumulators (1024 ints each) for the next call: srow / ccol are added to with atomics, so a call finds its
+// set zeroed by the call before (engine.hip: run_fx_u8c3 alternates two sets and clears a set itself when the geometry grew)
+__global__ __launch_bounds__(256) void fx_prepass(const uint8_t* __restrict__ src, int* __restrict__ srow, int* __restrict__ ccol, long long* __restrict__ zpart,
                                                   uint8_t* __restrict__ strips, int rows, int cols, int pad, int pada, int nbands, int nbatches, int n_alt, int chunks,
-                                                  int nright, int strip_blocks, int band_rows)
+                                                  int nright, int strip_blocks, int band_rows, int n_strip, int4* __restrict__ zero, int zero_int4s)
 {
     __shared__ int sred[kFxSumRows][3][64];
     int b = blockIdx.x;
     if (b < n_alt) {
         const int band = b % nbands, batch = (b / nbands) % nbatches, f = b / (nbands * nbatches);
-        fx_altsums_body(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
-    } else {
+        fx_altsums_body(src, srow, ccol, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
+    } else if (b < n_alt + n_strip) {
         b -= n_alt;
         const int nstrips = fx_left_strips(pada) + nright, bx = b % strip_blocks, sidx = (b / strip_blocks) % nstrips, f = b / (strip_blocks * nstrips);
         fx_edge_strips_body(src, strips, rows, cols, pada, chunks, nright, bx, sidx, f);
+    } else {
+        const int i = (b - n_alt - n_strip) * 256 + threadIdx.x;
+        if (i < zero_int4s) zero[i] = make_int4(0, 0, 0, 0);
     }
-}
-
-// grid (row blocks + value blocks + 1, frames), 256 threads.  Row blocks: qrow for 256 rows of V each (Srow = the batches' parts added
-// up).  Value blocks: ccol[f][e] = the bands' parts of Ccol added up, 256 values e = 3 x + c each.  The last block: zsum[f][c] = Z.
-__global__ __launch_bounds__(256) void fx_quirk_reduce(const int* __restrict__ srow_part, const int* __restrict__ cpart, const long long* __restrict__ zpart,
-                                                       float* __restrict__ qrow, int* __restrict__ ccol, double* __restrict__ zsum, int rows, int cols, int pad, int pada,
-                                                       int qrows, int nbands, int nbatches, int nrowblocks, int nvalblocks, float dr)
-{
-    const int f = blockIdx.y, tid = threadIdx.x;
-    if (static_cast<int>(blockIdx.x) < nrowblocks) {
-        const int re = blockIdx.x * 256 + tid;
-        if (re >= qrows) return;
-        const double sp = (pad & 1) ? -1.0 : 1.0;
-        const int r = mx_refl(re - pada, rows);
-        const int* sr = srow_part + (static_cast<size_t>(f) * nbatches * rows + r) * 3;
-        for (int c = 0; c < 3; ++c) {
-            int v = 0;
-            for (int b = 0; b < nbatches; ++b) v += sr[static_cast<size_t>(b) * rows * 3 + c];
-            qrow[(static_cast<size_t>(f) * 3 + c) * qrows + re] = static_cast<float>(static_cast<double>(dr) * sp * v);
-        }
-        return;
-    }
-    if (static_cast<int>(blockIdx.x) == nrowblocks + nvalblocks) {
-        __shared__ long long zs[3][256];
-        const int nz = nbands * nbatches;
-        long long z[3] = { 0, 0, 0 };
-        for (int i = tid; i < nz; i += 256)
-            for (int c = 0; c < 3; ++c) z[c] += zpart[(static_cast<size_t>(f) * nz + i) * 3 + c];
-        for (int c = 0; c < 3; ++c) zs[c][tid] = z[c];
-        __syncthreads();
-        for (int o = 128; o >= 1; o >>= 1) {
-            if (tid < o) for (int c = 0; c < 3; ++c) zs[c][tid] += zs[c][tid + o];
-            __syncthreads();
-        }
-        if (tid < 3) zsum[static_cast<size_t>(f) * 3 + tid] = static_cast<double>(zs[tid][0]);
-        return;
-    }
-    const int e = (blockIdx.x - nrowblocks) * 256 + tid;
-    if (e >= 3 * cols) return;
-    const int* cp = cpart + static_cast<size_t>(f) * nbands * (3 * cols) + e;
-    int sum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    int b = 0;
-    for (; b + 8 <= nbands; b += 8) {                       // eight independent loads per trip
-#pragma unroll
-        for (int j = 0; j < 8; ++j) sum[j] += cp[static_cast<size_t>(b + j) * (3 * cols)];
-    }
-    for (; b < nbands; ++b) sum[0] += cp[static_cast<size_t>(b) * (3 * cols)];
-    ccol[static_cast<size_t>(f) * 3 * cols + e] = ((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7]));
-}
-
-// grid (blocks of 256 values e = 3 x + c, frames), 256 threads: qcol = dc (-1)^pad (rowconv(Ccol)(x) + dr (-1)^(x+pad) Z), the row
-// convolution in double over an LDS tile of Ccol with the taps' reach on both sides (taps in LDS too).
-// taps: 2 pad + 1 floats, centre at pad.  dynamic LDS: nval ints + (2 pad + 1) floats
-__global__ __launch_bounds__(256) void fx_quirk_cols(const int* __restrict__ ccol, const double* __restrict__ zsum, const float* __restrict__ taps,
-                                                     float* __restrict__ qcol, int cols, int pad, int qpitch, int tileints, float dr, float dc)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char fxq_lds[];
-    const int f = blockIdx.y, tid = threadIdx.x;
-    const int e0 = blockIdx.x * 256;
-    // the tile: Ccol at the pixels xa .. xb = the block's pixels with the taps' reach on both sides, reflect-101 applied when it is
-    // filled, so the convolution loop is a plain dot product
-    const int xa = e0 / 3 - pad, xb = (e0 + 255) / 3 + pad, nval = 3 * (xb - xa + 1);
-    int* cc = reinterpret_cast<int*>(fxq_lds);
-    float* tp = reinterpret_cast<float*>(fxq_lds) + tileints;
-    for (int i = tid; i < nval; i += 256) {
-        const int xx = mx_refl(xa + i / 3, cols);
-        cc[i] = ccol[static_cast<size_t>(f) * 3 * cols + 3 * xx + i % 3];
-    }
-    for (int i = tid; i < 2 * pad + 1; i += 256) tp[i] = taps[i];
-    __syncthreads();
-    const int e = e0 + tid;
-    if (e >= qpitch) return;
-    const int x = e / 3, c = e - 3 * x;
-    float out = 0.f;
-    if (x < cols) {
-        const int* ccx = cc + 3 * (x - pad - xa) + c;              // tap t = -pad sits here
-        double acc[4] = { 0, 0, 0, 0 };
-        int t = 0;
-        for (; t + 4 <= 2 * pad + 1; t += 4) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += static_cast<double>(tp[t + j]) * ccx[3 * (t + j)];
-        }
-        for (; t <= 2 * pad; ++t) acc[0] += static_cast<double>(tp[t]) * ccx[3 * t];
-        const double sp = (pad & 1) ? -1.0 : 1.0, sx = ((x + pad) & 1) ? -1.0 : 1.0;
-        out = static_cast<float>(static_cast<double>(dc) * sp * (((acc[0] + acc[1]) + (acc[2] + acc[3])) + static_cast<double>(dr) * sx * zsum[static_cast<size_t>(f) * 3 + c]));
-    }
-    qcol[static_cast<size_t>(f) * qpitch + e] = out;
 }
 #endif  // BLUR_FX_QUIRK_KERNELS
 
 // ---- launcher ----------------------------------------------------------------------------------------------------------
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per DEVICE: remember per device which kernel sets have it (blur_multi_* drives
+// several devices from one process; a process-wide flag would raise the limit on the first device only).  Devices past 63: every call.
+inline bool fx_attr_needed(std::atomic<unsigned long long>& done, int& dev)
+{
+    dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+    return ((done.load(std::memory_order_acquire) >> dev) & 1ull) == 0;
+}
+inline void fx_attr_mark(std::atomic<unsigned long long>& done, int dev)
+{
+    if (dev >= 0 && dev < 64) done.fetch_or(1ull << dev, std::memory_order_release);
+}
+
 struct FxEntry {
     int nkb;
-    hipError_t (*blur_u8)(hipStream_t, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const float* qrow, const float* qcol, int qpitch,
-                          const uint8_t* strips, float* vdump);
+    // qk: the quirk's sums (null: nyquist_quirk = 0); vdump: the row pass's float planes (test instantiation); stamps: -DFX_STAMPS builds
+    hipError_t (*blur_u8)(hipStream_t, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const FxQuirk* qk, const uint8_t* strips,
+                          float* vdump, unsigned long long* stamps);
 };
 
-template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const float* qrow,
-                                           const float* qcol, int qpitch, const uint8_t* strips, float* vdump)
+template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, uint8_t* dst, const void* frags, FxGeom g, int num_cus, const FxQuirk* qk,
+                                           const uint8_t* strips, float* vdump, unsigned long long* stamps)
 {
     using C = FxCfg<NKB>;
     const int chunks = (g.cols + kFxChunk - 1) / kFxChunk;
@@ -868,21 +896,22 @@ template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, u
     if (g.nxcd < 1) g.nxcd = 1;
     const int per_xcd = static_cast<int>((ntasks + g.nxcd - 1) / g.nxcd);
     const dim3 grid(static_cast<unsigned>(g.nxcd * per_xcd));
-    static bool attr_done = false;
-    if (!attr_done) {
+    static std::atomic<unsigned long long> attr_done{ 0 };
+    int dev;
+    if (fx_attr_needed(attr_done, dev)) {
         const void* kernels[4] = { reinterpret_cast<const void*>(fx_blur_u8<NKB, true, false>), reinterpret_cast<const void*>(fx_blur_u8<NKB, false, false>),
                                    reinterpret_cast<const void*>(fx_blur_u8<NKB, true, true>), reinterpret_cast<const void*>(fx_blur_u8<NKB, false, true>) };
         for (const void* k : kernels) {
             const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
             if (e != hipSuccess) return e;
         }
-        attr_done = true;
+        fx_attr_mark(attr_done, dev);
     }
 #define FX_LAUNCH(Q_, D_)                                                                                                                                  \
     hipLaunchKernelGGL((fx_blur_u8<NKB, Q_, D_>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg,     \
-                       static_cast<int>(ntasks), qrow, qcol, qpitch, strips, vdump)
-    if (vdump) { if (qrow) FX_LAUNCH(true, true); else FX_LAUNCH(false, true); }
-    else { if (qrow) FX_LAUNCH(true, false); else FX_LAUNCH(false, false); }
+                       static_cast<int>(ntasks), qk ? *qk : FxQuirk{}, strips, vdump ? vdump : reinterpret_cast<float*>(stamps))
+    if (vdump) { if (qk) FX_LAUNCH(true, true); else FX_LAUNCH(false, true); }
+    else { if (qk) FX_LAUNCH(true, false); else FX_LAUNCH(false, false); }
 #undef FX_LAUNCH
     return hipGetLastError();
 }
