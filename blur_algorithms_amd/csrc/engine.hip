@@ -665,10 +665,8 @@ struct blur_ctx {
     std::map<std::tuple<int, int, int, int, int, uint64_t>, MxTables> mx_tables;   // (ksize | -1, pad, nkb, n_row, n_col, sigma bits | hash)
     uint8_t* fx_strips = nullptr;   // fused kernel: the edge chunks' windows with the mirrored pixels in place
     size_t fx_strips_bytes = 0;
-    int* fx_acc = nullptr;          // fused kernel, quirk: two sets of integer accumulators + the parts of Z (run_fx_u8c3)
-    size_t fx_acc_ints = 0, fx_z_count = 0;
-    size_t fx_acc_clear[2] = { 0, 0 };   // leading ints of each set known to be zero
-    int fx_acc_phase = 0;
+    int* fx_sums = nullptr;         // fused kernel, quirk: the pre-pass's partial sums (run_fx_u8c3)
+    size_t fx_sums_bytes = 0;
     int* mx_sums = nullptr;
     size_t mx_sums_bytes = 0;
     float* mx_terms = nullptr;
@@ -1522,7 +1520,7 @@ int blur_ctx_destroy(blur_ctx* ctx)
     }
     for (auto& lt : ctx->lines_tables) (void)hipFree(lt.dev);
     if (ctx->fx_strips) (void)hipFree(ctx->fx_strips);
-    if (ctx->fx_acc) (void)hipFree(ctx->fx_acc);
+    if (ctx->fx_sums) (void)hipFree(ctx->fx_sums);
     if (ctx->mx_sums) (void)hipFree(ctx->mx_sums);
     if (ctx->mx_terms) (void)hipFree(ctx->mx_terms);
     if (ctx->work) (void)hipFree(reinterpret_cast<char*>(ctx->work) - kWorkGuard);
@@ -1677,47 +1675,36 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     if (!p.mx_quirk) {
         TimedLaunch t(ctx, 1, nframes);
         hipLaunchKernelGGL(fx_prepass, dim3(n_strip), dim3(256), 0, ctx->stream, d_src, nullptr, nullptr, nullptr, ctx->fx_strips, rows, cols, p.sz.pad, pada, 1, 1, 0, chunks_x,
-                           g.nright, strip_blocks, kFxSumRows, n_strip, nullptr, 0);
+                           g.nright, strip_blocks, kFxSumRows);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (p.mx_quirk) {
-        // The quirk's sums.  Two sets of accumulators {srow [frame][row][3], ccol [frame][3 cols]} (ints, added to with atomics by the
-        // pre-pass) used in turn: a call's pre-pass clears the other set for the call after it; a set this call cannot know to be
-        // clear (first use, or the geometry grew) is cleared here.  zpart [frame][band][batch][3] (64-bit) is plainly stored.
+        // the quirk's partial sums (exact integers): srow_part [frame][batch][row][3], cpart [frame][band][3 cols], zpart (64-bit)
+        // [frame][band][batch][3]; the fused kernel adds them up where it needs them (struct FxQuirk)
         const int band_rows = fx_band_rows(rows, cols, nframes, ctx->num_cus), nbands = (rows + band_rows - 1) / band_rows, nbatches = (cols / 4 + 255) / 256;
         auto up4 = [](size_t v) { return (v + 3) & ~static_cast<size_t>(3); };
-        const size_t n_srow = up4(static_cast<size_t>(nframes) * rows * 3), n_ccol = up4(static_cast<size_t>(nframes) * 3 * cols), n_acc = n_srow + n_ccol;
+        const size_t n_srow = up4(static_cast<size_t>(nframes) * nbatches * rows * 3), n_cpart = up4(static_cast<size_t>(nframes) * nbands * 3 * cols);
         const size_t n_z = static_cast<size_t>(nframes) * nbands * nbatches * 3;
-        if (ctx->fx_acc_ints < n_acc || ctx->fx_z_count < n_z) {
-            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-            if (ctx->fx_acc) { HIP_TRY(ctx, hipFree(ctx->fx_acc)); ctx->fx_acc = nullptr; }
-            ctx->fx_acc_ints = ctx->fx_z_count = 0;
-            const size_t cap = up4(n_acc + n_acc / 8), zcap = n_z + n_z / 8 + 8;
-            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->fx_acc), (2 * cap) * sizeof(int) + zcap * sizeof(long long)));
-            ctx->fx_acc_ints = cap;
-            ctx->fx_z_count = zcap;
-            ctx->fx_acc_clear[0] = ctx->fx_acc_clear[1] = 0;
+        const size_t bytes = (n_srow + n_cpart) * sizeof(int) + n_z * sizeof(long long) + 64;
+        if (ctx->fx_sums_bytes < bytes) {
+            if (ctx->fx_sums) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->fx_sums)); ctx->fx_sums = nullptr; ctx->fx_sums_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->fx_sums), bytes + bytes / 8));
+            ctx->fx_sums_bytes = bytes + bytes / 8;
         }
-        const int cur = ctx->fx_acc_phase & 1;
-        int* acc = ctx->fx_acc + static_cast<size_t>(cur) * ctx->fx_acc_ints;
-        int* other = ctx->fx_acc + static_cast<size_t>(cur ^ 1) * ctx->fx_acc_ints;
-        long long* zpart = reinterpret_cast<long long*>(ctx->fx_acc + 2 * ctx->fx_acc_ints);
-        if (ctx->fx_acc_clear[cur] < n_acc) HIP_TRY(ctx, hipMemsetAsync(acc, 0, n_acc * sizeof(int), ctx->stream));
-        int* srow = acc;
-        int* ccol = acc + n_srow;
+        int* srow = ctx->fx_sums;
+        int* cpart = srow + n_srow;                                                     // 16-byte aligned: int4 stores
+        long long* zpart = reinterpret_cast<long long*>(cpart + n_cpart);
         { TimedLaunch t(ctx, 1, nframes);
-          const int n_alt = nbands * nbatches * nframes, zero_int4s = static_cast<int>(n_acc / 4), n_zero = (zero_int4s + 255) / 256;
-          hipLaunchKernelGGL(fx_prepass, dim3(n_alt + n_strip + n_zero), dim3(256), 0, ctx->stream, d_src, srow, ccol, zpart, ctx->fx_strips, rows, cols, p.sz.pad, pada, nbands,
-                             nbatches, n_alt, chunks_x, g.nright, strip_blocks, band_rows, n_strip, reinterpret_cast<int4*>(other), zero_int4s);
+          const int n_alt = nbands * nbatches * nframes;
+          hipLaunchKernelGGL(fx_prepass, dim3(n_alt + n_strip), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, ctx->fx_strips, rows, cols, p.sz.pad, pada, nbands,
+                             nbatches, n_alt, chunks_x, g.nright, strip_blocks, band_rows);
           HIP_TRY(ctx, hipGetLastError()); }
-        ctx->fx_acc_clear[cur] = 0;
-        ctx->fx_acc_clear[cur ^ 1] = n_acc;
-        ctx->fx_acc_phase ^= 1;
-        qk.srow = srow;
-        qk.ccol = ccol;
+        qk.srow_part = srow;
+        qk.cpart = cpart;
         qk.zpart = zpart;
         qk.taps = p.mxt->taps_row;
-        qk.nz = nbands * nbatches;
+        qk.nbatches = nbatches;
+        qk.nbands = nbands;
         qk.dr = p.mxt->dr;
         qk.dc = p.mxt->dc;
     }

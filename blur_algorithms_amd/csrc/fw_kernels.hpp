@@ -115,7 +115,12 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
             raw[k][0] = t[0]; raw[k][1] = t[1]; raw[k][2] = t[2];
         }
         if (QUIRK && tid < 32)          // the row term of row re of V (= image row refl(re - PADA)): dr (-1)^pad Srow
-            qraw = static_cast<float>(qrs * qk.srow[(static_cast<size_t>(f) * g.rows + mx_refl(min(32 * s + tid, qrows - 1) - PADA, g.rows)) * 3 + c]);
+        {
+            const int* sp = qk.srow_part + (static_cast<size_t>(f) * qk.nbatches * g.rows + mx_refl(min(32 * s + tid, qrows - 1) - PADA, g.rows)) * 3 + c;
+            int v = 0;
+            for (int b = 0; b < qk.nbatches; ++b) v += sp[static_cast<size_t>(b) * g.rows * 3];
+            qraw = static_cast<float>(qrs * v);
+        }
     };
     // channel c of group k -> binary16 subnormals -> LDS: two v_perm_b32 (run-time selectors: the channel is the task's) and one
     // ds_write_b64.  Pixels (0, 1) of the group are bytes (c, 3 + c), pixels (2, 3) bytes (6 + c, 9 + c) of its three dwords.

@@ -98,41 +98,52 @@ __device__ __forceinline__ uint32_t fx_quad_transpose(uint32_t p, uint32_t sel1,
 }
 
 // What the fused kernels need for the Nyquist-slot quirk (Source.cpp:420-425; the algebra is at fx_altsums_body): the pre-pass's
-// exact integer sums, complete when the fused kernel starts, and the taps.  The kernels turn them into their terms themselves:
-//   row term      qrow(r, c) = dr (-1)^pad Srow(r, c), added to V as qrow (-1)^x                    (one load + three conversions per row)
+// exact integer partial sums and the taps.  The kernels turn them into their terms themselves:
+//   row term      qrow(r, c) = dr (-1)^pad Srow(r, c), added to V as qrow (-1)^x           (the row's batch parts: a few loads per row)
 //   column term   qcol(x, c) = dc (-1)^pad (rowconv(Ccol)(x, c) + dr (-1)^(x+pad) Z(c)), added to the output as qcol (-1)^r: a
-//                 workgroup convolves the 128 + 2 pad values of Ccol around its own chunk in its prologue (fx_quirk_cols_tile)
-// so a call is two launches (pre-pass, fused kernel); rounds 2-3 had two more kernels for the terms between them.
+//                 workgroup adds up the bands' parts of the 128 + 2 pad values of Ccol around its own chunk and convolves them in
+//                 its prologue (fx_quirk_cols_tile)
+// so a call is two launches (pre-pass, fused kernel); rounds 2-3 had two more kernels for the terms between them (13 us and two
+// launch gaps per call; the prologue costs the fused kernel a few us).
 struct FxQuirk {
-    const int* srow;            // [frame][row][3]      Srow(r, c) = sum_x wx(x) img[r][x][c]
-    const int* ccol;            // [frame][3 x + c]     Ccol(x, c) = sum_r wy(r) img[r][x][c]
-    const long long* zpart;     // [frame][nz][3]       parts of Z(c) = sum_r wy(r) Srow(r, c)
+    const int* srow_part;       // [frame][batch][row][3]    parts of Srow(r, c) = sum_x wx(x) img[r][x][c]
+    const int* cpart;           // [frame][band][3 x + c]    parts of Ccol(x, c) = sum_r wy(r) img[r][x][c]
+    const long long* zpart;     // [frame][band][batch][3]   parts of Z(c) = sum_r wy(r) Srow(r, c)
     const float* taps;          // the 2 pad + 1 taps of the row pass, centre at pad
-    int nz;
+    int nbatches, nbands;
     float dr, dc;
 };
 
 // qc[NCH xl + c] (xl = 0 .. 127; NCH = 3: c = 0 .. 2, NCH = 1: channel c0 only) = the column term of pixel x0 + xl, 0 right of the
-// image.  256 threads; `scratch` = LDS for NCH (128 + 2 pad) ints + (2 pad + 1) floats + 4 doubles; ends with a barrier, after which
-// scratch is free again and qc is valid.  The convolution runs in double over the LDS tile (reflect-101 applied when it is filled).
+// image.  256 threads; `scratch` = LDS for NCH (128 + 2 pad) + 2 pad + 1 + 4 doubles; ends with a barrier, after which scratch is free
+// again and qc is valid.  One wave per SIMD hides no latency, so: independent loads in batches of eight, every value converted to
+// double ONCE when it enters LDS, and the convolution (in double, reflect-101 applied when the tile is filled) eight taps per trip.
 template <int NCH>
 __device__ __forceinline__ void fx_quirk_cols_tile(unsigned char* scratch, float* qc, const FxQuirk& q, int f, int x0, int c0, int cols, int pad, int tid)
 {
     const int win = kFxChunk + 2 * pad, nval = NCH * win, ntap = 2 * pad + 1;
-    int* cc = reinterpret_cast<int*>(scratch);
-    float* tp = reinterpret_cast<float*>(cc + nval);
-    double* zs = reinterpret_cast<double*>(scratch + ((static_cast<size_t>(nval + ntap) * 4 + 7) & ~static_cast<size_t>(7)));
+    double* cc = reinterpret_cast<double*>(scratch);
+    double* tp = cc + nval;
+    double* zs = tp + ntap;
+    const size_t bstride = static_cast<size_t>(3) * cols;
     for (int i = tid; i < nval; i += 256) {
         const int p = i / NCH, ch = NCH == 3 ? i - 3 * p : c0;
-        cc[i] = q.ccol[static_cast<size_t>(f) * 3 * cols + 3 * mx_refl(x0 - pad + p, cols) + ch];
+        const int* cp = q.cpart + static_cast<size_t>(f) * q.nbands * bstride + 3 * mx_refl(x0 - pad + p, cols) + ch;
+        int sum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+        int b = 0;
+        for (; b + 8 <= q.nbands; b += 8) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum[j] += cp[(b + j) * bstride];
+        }
+        for (; b < q.nbands; ++b) sum[0] += cp[b * bstride];
+        cc[i] = static_cast<double>(((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7])));
     }
-    for (int i = tid; i < ntap; i += 256) tp[i] = q.taps[i];
+    for (int i = tid; i < ntap; i += 256) tp[i] = static_cast<double>(q.taps[i]);
     {   // Z: wave w < 3 adds up channel w's parts (exact integers), a lane per part, then across the wave
-        const int w = tid >> 6, l = tid & 63;
+        const int w = tid >> 6, l = tid & 63, nz = q.nbands * q.nbatches;
         if (w < 3 && (NCH == 3 || w == c0)) {
             long long z = 0;
-            for (int i = l; i < q.nz; i += 64) z += q.zpart[(static_cast<size_t>(f) * q.nz + i) * 3 + w];
-#pragma unroll
+            for (int i = l; i < nz; i += 64) z += q.zpart[(static_cast<size_t>(f) * nz + i) * 3 + w];
             for (int o = 32; o >= 1; o >>= 1) z += __shfl_xor(z, o, 64);
             if (l == 0) zs[w] = static_cast<double>(z);
         }
@@ -143,14 +154,17 @@ __device__ __forceinline__ void fx_quirk_cols_tile(unsigned char* scratch, float
         const int xl = e / NCH, c = NCH == 3 ? e - 3 * xl : c0, x = x0 + xl;
         float out = 0.f;
         if (x < cols) {
-            const int* ccx = cc + NCH * xl + (NCH == 3 ? c : 0);              // tap t = -pad sits here
+            const double* ccx = cc + NCH * xl + (NCH == 3 ? c : 0);           // tap t = -pad sits here
             double acc[4] = { 0, 0, 0, 0 };
             int t = 0;
-            for (; t + 4 <= ntap; t += 4) {
+            for (; t + 8 <= ntap; t += 8) {
+                double a[8], v[8];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[j] += static_cast<double>(tp[t + j]) * ccx[NCH * (t + j)];
+                for (int j = 0; j < 8; ++j) { a[j] = tp[t + j]; v[j] = ccx[NCH * (t + j)]; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j & 3] = __builtin_fma(a[j], v[j], acc[j & 3]);
             }
-            for (; t < ntap; ++t) acc[0] += static_cast<double>(tp[t]) * ccx[NCH * t];
+            for (; t < ntap; ++t) acc[t & 3] = __builtin_fma(tp[t], ccx[NCH * t], acc[t & 3]);
             const double sx = ((x + pad) & 1) ? -1.0 : 1.0;
             out = static_cast<float>(static_cast<double>(q.dc) * sp * (((acc[0] + acc[1]) + (acc[2] + acc[3])) + static_cast<double>(q.dr) * sx * zs[c]));
         }
@@ -278,7 +292,10 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
         if (QUIRK && j == 0 && tid < 96) {
             // the row term of row re of V (= image row refl(re - PADA)): dr (-1)^pad Srow, rounded once as the term kernels of rounds 2-3 did
             const int c = tid >> 5, re = min(32 * s + (tid & 31), qrows - 1);
-            qraw = static_cast<float>(qrs * qk.srow[(static_cast<size_t>(f) * g.rows + mx_refl(re - PADA, g.rows)) * 3 + c]);
+            const int* sp = qk.srow_part + (static_cast<size_t>(f) * qk.nbatches * g.rows + mx_refl(re - PADA, g.rows)) * 3 + c;
+            int v = 0;
+            for (int b = 0; b < qk.nbatches; ++b) v += sp[static_cast<size_t>(b) * g.rows * 3];
+            qraw = static_cast<float>(qrs * v);
         }
     };
     // one (group k, channel c) of the window: two v_perm_b32 (deinterleave + the low byte of a binary16 each) and one ds_write_b64
@@ -560,9 +577,14 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
                             if (kb == 2) { split_piece(cur, c, 3); split_piece(cur, c, 5); }
                             if (kb == 3) split_piece(cur, c, 6);
                             if (kb == 4) split_piece(cur, c, 7);
+#ifdef FX_NO_BALANCE
                             if (kb >= 2) commit_item(cbuf, 3 * jc + (kb - 2) / 3, (kb - 2) % 3);
                             if (c == 0 && kb >= 5 && kb <= 8) store_group(s - 1 - NT, tvalid, kb - 5);
                             if (kb == NKB - 1) { if (jc == 0) commit_q(cbuf); issue_chunk(snext, jc); }
+#else
+                            // (the staging and the stores ride in phase B: A's two products per block leave room for the hand-off only)
+                            (void)tvalid; (void)jc; (void)cbuf; (void)snext;
+#endif
                         } else {
                             if (kb == 0) { split_piece(cur, c, 1); split_piece(cur, c, 2); split_piece(cur, c, 3); split_piece(cur, c, 5); split_piece(cur, c, 6); split_piece(cur, c, 7); }
 #pragma unroll
@@ -587,6 +609,22 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
                             if (it == 1) split_piece(nbuf, nc, 0, c == 2 ? s + 1 : s);
                             if (it == 2) split_piece(nbuf, nc, 4, c == 2 ? s + 1 : s);
                             if (it >= 3 && it <= 6) emit_piece(c, it - 3);
+#ifndef FX_NO_BALANCE
+                            // B has three products per slot and less to do beside them than A: the staging chunk of this product
+                            // (c == 2: chunk 0 of window s + 2 -> buffer cur, which the barrier before A(s, 2) freed; c == 0, 1: chunk
+                            // c + 1 of window s + 1 -> buffer cur ^ 1, complete before that barrier) in slots 0, 7 .. 10, its re-issue
+                            // last; the stores of the tile this step finishes (all three channels emitted by slot 6 of c == 2) in 7 .. 10
+                            {
+                                const int jc = c == 2 ? 0 : c + 1, cbuf = c == 2 ? cur : cur ^ 1, snext = c == 2 ? s + 3 : s + 2;
+                                const int sl = it == 0 ? 0 : it - 6;                       // 0, 1 .. 4
+                                if (it == 0 || it >= 7) {
+                                    commit_item(cbuf, 3 * jc + (2 * sl) / 3, (2 * sl) % 3);
+                                    if (sl < 4) commit_item(cbuf, 3 * jc + (2 * sl + 1) / 3, (2 * sl + 1) % 3);
+                                }
+                                if (c == 2 && it >= 7) store_group(s - NT, s - NT >= tile0, it - 7);
+                                if (it == NKB - 1) { if (jc == 0) commit_q(cbuf); issue_chunk(snext, jc); }
+                            }
+#endif
                         } else {
                             if (it == (NKB >= 5 ? 1 : 0)) { split_piece(nbuf, nc, 0, c == 2 ? s + 1 : s); split_piece(nbuf, nc, 4, c == 2 ? s + 1 : s); }
                             if (it == (NKB >= 5 ? NKB - 3 : 0)) {
@@ -604,7 +642,10 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
             }
         }
     }
-    store_tile(s1 - 1 - NT, s1 - 1 - NT >= tile0);
+    if (NKB < 11) store_tile(s1 - 1 - NT, s1 - 1 - NT >= tile0);
+#ifdef FX_NO_BALANCE
+    else store_tile(s1 - 1 - NT, s1 - 1 - NT >= tile0);          // (otherwise step s1 - 1 stored it in its last phase B)
+#endif
 #ifdef FX_STAMPS
     if (!QUIRK && !DUMPV && vdump && blockIdx.x == 0 && tid == 0) {        // (timing-only build: vdump carries the stamp buffer)
         unsigned long long* o = reinterpret_cast<unsigned long long*>(vdump);
@@ -690,8 +731,9 @@ __device__ __forceinline__ void fx_edge_strips_body(const uint8_t* __restrict__ 
 }
 
 constexpr int kFxSumRows = 32;          // image rows per sub-band (packed 16-bit column sums: 32 x 3 x 255 < 65536)
-// rows per workgroup of the pre-pass: sub-bands of 32 (16 for small frames: twice the workgroups, each half as long).  Every band adds
-// its column sums to Ccol with atomics (12 wave-instructions per wave), so tall bands where the batch still gives four workgroups per CU
+// rows per workgroup of the pre-pass: sub-bands of 32 (16 for small frames: twice the workgroups, each half as long).  Every band
+// leaves a part of the column sums that every fused workgroup adds up for its own columns: tall bands where the batch still gives
+// four workgroups per CU
 inline int fx_band_rows(int rows, int cols, int nframes, int num_cus)
 {
     if (static_cast<long long>(rows) * cols < 4000000ll) return 16;
@@ -703,15 +745,14 @@ inline int fx_band_rows(int rows, int cols, int nframes, int num_cus)
 
 // workgroup (band of band_rows rows, batch of 256 twelve-byte groups = 1024 pixel columns, frame), 256 threads: a thread owns one
 // group (4 pixels) of every row of the band, eight rows of loads in flight; cols % 4 == 0, frames 4-byte aligned.  Exact integers:
-//   srow[f][r][c]            += sum over the batch's pixels of wx(x) img[r][x][c]        (atomics: the batches of a row)
-//   ccol[f][3 x + c]         += sum over the band's rows of wy(r) img[r][x][c]           (atomics: the bands of a column; a wave
-//                                                                                         instruction adds 256 contiguous bytes)
-//   zpart[f][band][batch][c]  = sum over the band's rows of wy(r) x (the batch's part of Srow(r, c))     (plain stores)
-// so Srow and Ccol are complete when the launch ends and nothing has to be reduced between it and the fused kernel.  (Integer
-// atomics: the result does not depend on the order.  They execute at the memory side, device scope: the XCDs' L2s are not coherent.)
+//   srow_part[f][batch][r][c]  sum over the batch's pixels of wx(x) img[r][x][c]
+//   cpart[f][band][3 x + c]    sum over the band's rows of wy(r) img[r][x][c]
+//   zpart[f][band][batch][c]   sum over the band's rows of wy(r) srow_part[f][batch][r][c]       (the parts of Z)
+// (Adding the parts up with atomics instead -- Srow and Ccol complete when the launch ends -- was measured: the 3 M atomic adds of
+// an 8 x 4K batch cost the pre-pass 16 us, more than the consumers' few extra loads.)
 // sred[row][channel][lane]: lane l of every wave adds into slot l (one conflict-free ds_add_u32 per value: a same-address atomic the
 // compiler would turn into a serial loop over the lanes, and a DPP reduction costs twelve dependent instructions)
-__device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src, int* __restrict__ srow, int* __restrict__ ccol, long long* __restrict__ zpart,
+__device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
                                                 int rows, int cols, int pad, int nbands, int nbatches, int band, int batch, int f, int (*sred)[3][64], int band_rows)
 {
     const int tid = threadIdx.x;
@@ -799,28 +840,20 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
             int v = 0;
 #pragma unroll
             for (int k = 0; k < 64; ++k) v += p64[(k + tid) & 63];              // (rotated: the 96 threads start on different banks)
-            atomicAdd(&srow[(static_cast<size_t>(f) * rows + rs) * 3 + tid], v);
+            srow_part[((static_cast<size_t>(f) * nbatches + batch) * rows + rs) * 3 + tid] = v;
             zacc += static_cast<long long>(mx_alt_weight(rs + tid / 3, rows, pad)) * v;
         }
         __syncthreads();                                                   // sred is zeroed again / reused below
     }
-    // the column sums: through LDS so that a wave's atomic instruction covers 64 consecutive ints (a lane's own 12 lie 48 bytes
-    // from its neighbour's: scattered atomics run at a fraction of the rate); then Z's part of this workgroup
-    int* ex = &sred[0][0][0];
-#pragma unroll
-    for (int j = 0; j < 12; ++j) ex[12 * tid + j] = o[j];
-    long long* zs = reinterpret_cast<long long*>(ex + 12 * 256);
+    if (act) {
+        int4* dstp = reinterpret_cast<int4*>(cpart + (static_cast<size_t>(f) * nbands + band) * (3 * cols) + 12 * gi);
+        dstp[0] = make_int4(o[0], o[1], o[2], o[3]);
+        dstp[1] = make_int4(o[4], o[5], o[6], o[7]);
+        dstp[2] = make_int4(o[8], o[9], o[10], o[11]);
+    }
+    long long* zs = reinterpret_cast<long long*>(&sred[0][0][0]);          // (the last sub-band's barrier has passed: sred is free)
     if (tid < 96) zs[tid] = zacc;
     __syncthreads();
-    {
-        const int first = 12 * 256 * batch, lim = 3 * cols - first;        // ints of this batch inside the row of 3 cols
-        int* cdst = ccol + static_cast<size_t>(f) * 3 * cols + first;
-#pragma unroll
-        for (int j = 0; j < 12; ++j) {
-            const int idx = 256 * j + tid;
-            if (idx < lim) atomicAdd(&cdst[idx], ex[idx]);
-        }
-    }
     if (tid < 3) {
         long long z = 0;
         for (int k = 0; k < kFxSumRows; ++k) z += zs[3 * k + tid];
@@ -829,25 +862,20 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
 }
 
 // One launch for everything that has to happen before the fused kernel: the quirk's sums (n_alt = bands x batches x frames workgroups,
-// none with nyquist_quirk = 0), the edge strips (strip_blocks x nstrips x frames workgroups), and last in the grid n_zero workgroups that
-// clear the OTHER set of accumulators (1024 ints each) for the next call: srow / ccol are added to with atomics, so a call finds its
-// set zeroed by the call before (engine.hip: run_fx_u8c3 alternates two sets and clears a set itself when the geometry grew)
-__global__ __launch_bounds__(256) void fx_prepass(const uint8_t* __restrict__ src, int* __restrict__ srow, int* __restrict__ ccol, long long* __restrict__ zpart,
+// none with nyquist_quirk = 0) and the edge strips (strip_blocks x nstrips x frames workgroups, last in the grid: they fill the tail)
+__global__ __launch_bounds__(256) void fx_prepass(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
                                                   uint8_t* __restrict__ strips, int rows, int cols, int pad, int pada, int nbands, int nbatches, int n_alt, int chunks,
-                                                  int nright, int strip_blocks, int band_rows, int n_strip, int4* __restrict__ zero, int zero_int4s)
+                                                  int nright, int strip_blocks, int band_rows)
 {
     __shared__ int sred[kFxSumRows][3][64];
     int b = blockIdx.x;
     if (b < n_alt) {
         const int band = b % nbands, batch = (b / nbands) % nbatches, f = b / (nbands * nbatches);
-        fx_altsums_body(src, srow, ccol, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
-    } else if (b < n_alt + n_strip) {
+        fx_altsums_body(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
+    } else {
         b -= n_alt;
         const int nstrips = fx_left_strips(pada) + nright, bx = b % strip_blocks, sidx = (b / strip_blocks) % nstrips, f = b / (strip_blocks * nstrips);
         fx_edge_strips_body(src, strips, rows, cols, pada, chunks, nright, bx, sidx, f);
-    } else {
-        const int i = (b - n_alt - n_strip) * 256 + threadIdx.x;
-        if (i < zero_int4s) zero[i] = make_int4(0, 0, 0, 0);
     }
 }
 #endif  // BLUR_FX_QUIRK_KERNELS

@@ -14,6 +14,7 @@ cp "$SRC"/build/*.o "$OUT"/
 for f in $FILES; do
     extra2=""
     [ "$f" = "bx_box.hip" ] && extra2="-mllvm -amdgpu-mfma-vgpr-form=1"
+    case "$f" in fx_conv_*) extra2="-mllvm -pragma-unroll-threshold=100000";; esac
     (cd "$SRC" && /opt/rocm/bin/hipcc $FLAGS $extra2 $EXTRA -c "$f" -o "$OUT/${f%.hip}.o") &
 done
 wait
