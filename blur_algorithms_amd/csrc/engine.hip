@@ -1201,6 +1201,7 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         // (0xfffffff0 is the offset the kernels give a dropped store: it must lie outside the frame's buffer resource)
         else if (static_cast<long long>(rows) * cols * 3 > 0xfffffff0ll) why = "fused matrix-core engine: frame too large for 32-bit offsets";
         else if ((cols & 3) != 0) why = "fused matrix-core engine: the image width must be a multiple of 4";
+        else if (quirk && fx_groups_per_thread(cols) == 0) why = "fused matrix-core engine: image wider than 16384 pixels (the quirk's pre-pass)";
         else if (!ptrs_aligned) why = "fused matrix-core engine: frame pointers must be 4-byte aligned";
         if (why && choice == BLUR_ENGINE_FUSED) return fail(ctx, BLUR_ERR_UNSUPPORTED, why);
         if (!why) {
@@ -1675,13 +1676,14 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     if (!p.mx_quirk) {
         TimedLaunch t(ctx, 1, nframes);
         hipLaunchKernelGGL(fx_prepass, dim3(n_strip), dim3(256), 0, ctx->stream, d_src, nullptr, nullptr, nullptr, ctx->fx_strips, rows, cols, p.sz.pad, pada, 1, 1, 0, chunks_x,
-                           g.nright, strip_blocks, kFxSumRows);
+                           g.nright, strip_blocks, kFxSumRows, 1);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (p.mx_quirk) {
         // the quirk's partial sums (exact integers): srow_part [frame][batch][row][3], cpart [frame][band][3 cols], zpart (64-bit)
         // [frame][band][batch][3]; the fused kernel adds them up where it needs them (struct FxQuirk)
-        const int band_rows = fx_band_rows(rows, cols, nframes, ctx->num_cus), nbands = (rows + band_rows - 1) / band_rows, nbatches = (cols / 4 + 255) / 256;
+        const int gpt = fx_groups_per_thread(cols);
+        const int band_rows = fx_band_rows(rows, cols, nframes, ctx->num_cus), nbands = (rows + band_rows - 1) / band_rows, nbatches = (cols / 4 + 256 * gpt - 1) / (256 * gpt);
         auto up4 = [](size_t v) { return (v + 3) & ~static_cast<size_t>(3); };
         const size_t n_srow = up4(static_cast<size_t>(nframes) * nbatches * rows * 3), n_cpart = up4(static_cast<size_t>(nframes) * nbands * 3 * cols);
         const size_t n_z = static_cast<size_t>(nframes) * nbands * nbatches * 3;
@@ -1697,7 +1699,7 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         { TimedLaunch t(ctx, 1, nframes);
           const int n_alt = nbands * nbatches * nframes;
           hipLaunchKernelGGL(fx_prepass, dim3(n_alt + n_strip), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, ctx->fx_strips, rows, cols, p.sz.pad, pada, nbands,
-                             nbatches, n_alt, chunks_x, g.nright, strip_blocks, band_rows);
+                             nbatches, n_alt, chunks_x, g.nright, strip_blocks, band_rows, gpt);
           HIP_TRY(ctx, hipGetLastError()); }
         qk.srow_part = srow;
         qk.cpart = cpart;

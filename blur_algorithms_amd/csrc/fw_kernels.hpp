@@ -98,7 +98,7 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
     const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wbase), 0, wbytes, kMxRsrcWord3);
     const int srow = tid >> 3, g0 = tid & 7;
     uint32_t raw[PER][3];
-    float qraw = 0.f;
+    int qpart[kFxMaxBatches] = {};
     // the window of step s: thread t moves the twelve-byte groups (t & 7) + 8 k of row t >> 3, all requested at once (consumed one
     // matrix-heavy pass later).  (A mapping with 2 rows x 384 contiguous bytes per wave load instead of 8 x 96 changed nothing.)
     auto issue_window = [&](int s) __attribute__((always_inline)) {
@@ -117,9 +117,8 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
         if (QUIRK && tid < 32)          // the row term of row re of V (= image row refl(re - PADA)): dr (-1)^pad Srow
         {
             const int* sp = qk.srow_part + (static_cast<size_t>(f) * qk.nbatches * g.rows + mx_refl(min(32 * s + tid, qrows - 1) - PADA, g.rows)) * 3 + c;
-            int v = 0;
-            for (int b = 0; b < qk.nbatches; ++b) v += sp[static_cast<size_t>(b) * g.rows * 3];
-            qraw = static_cast<float>(qrs * v);
+#pragma unroll
+            for (int b = 0; b < kFxMaxBatches; ++b) qpart[b] = sp[static_cast<size_t>(min(b, qk.nbatches - 1)) * g.rows * 3];      // (fx_kernels.hpp: issue_chunk)
         }
     };
     // channel c of group k -> binary16 subnormals -> LDS: two v_perm_b32 (run-time selectors: the channel is the task's) and one
@@ -141,6 +140,10 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
     };
     auto commit_q = [&](int buf) __attribute__((always_inline)) {
         if (QUIRK && tid < 32) {
+            int v = qpart[0];
+#pragma unroll
+            for (int b = 1; b < kFxMaxBatches; ++b) v += b < qk.nbatches ? qpart[b] : 0;
+            const float qraw = static_cast<float>(qrs * v);
             float* qs = reinterpret_cast<float*>(fw_lds + C::QOFF) + buf * 64 + tid;
             qs[0] = qraw;            // the term enters as qrow (-1)^x: lanes of even x read this copy,
             qs[32] = -qraw;          // lanes of odd x this one

@@ -53,16 +53,21 @@ struct FxGeom {
 };
 
 constexpr int kFxChunk = 128;     // pixel columns per workgroup
+constexpr int kFxMaxBatches = 4;  // column batches of the quirk's pre-pass = parts of a row's alternating sum (fx_prepass)
 // chunks at the left edge whose window (from 128 xc - pada) starts left of the image: they read a strip
 __host__ __device__ constexpr int fx_left_strips(int pada) { return pada > 0 ? (pada + kFxChunk - 1) / kFxChunk : 1; }
 
 template <int NKB> struct FxCfg {
     static constexpr int PADA = 8 * (NKB - 2), WIN = kFxChunk + 2 * PADA, GPR = WIN / 4, PER = (GPR + 7) / 8;
-    static constexpr int PW = mx_row_pitch(NKB);                     // halfs per LDS row of the window
+    // halfs per LDS row of the window: every thread commits PER groups of 4 positions, 32 apart, WITHOUT a lane mask (an exec-masked
+    // commit is a branch in the middle of a slice of matrix instructions: the slice's vector work then runs behind them instead of
+    // beside them), so a row holds 32 PER positions; pitch = 4 mod 8 dwords as in mx_row_pitch (conflict-free ds_read_b128)
+    static constexpr int fx_pitch() { int dw = 16 * PER; while ((dw & 7) != 4) ++dw; return 2 * dw; }
+    static constexpr int PW = fx_pitch();
     static constexpr int NT = (NKB - 1) / 2;                          // live accumulator tiles per channel = steps per unrolled round
     static constexpr int BUF = 3 * 32 * PW * 2;                       // bytes of one window buffer
-    static constexpr int QOFF = 2 * BUF;                              // qrow stage: [2 buffers][x even, odd: +q, -q][3][32] floats
-    static constexpr int LDS = QOFF + 2 * 2 * 96 * 4;
+    static constexpr int QOFF = 2 * BUF;                              // qrow stage: [2 buffers][x even, odd: +q, -q][256] floats (96 used:
+    static constexpr int LDS = QOFF + 2 * 2 * 256 * 4;                // [3][32]; every thread stores, threads 96 .. 255 into the padding)
 };
 
 // x as binary16: the byte in the low half of a binary16 is the SUBNORMAL x * 2^-24 -- the matrix cores take subnormal
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     // step s handles rows 32 s .. 32 s + 31 of V (row re of V = image row refl(re - PADA)) and emits tile s - NT
     const int s0 = tile0, s1 = tile1 + NT;
     FxRaw<NKB> raw;
-    float qraw = 0.f;
+    int qpart[kFxMaxBatches] = {};
     // staging in three chunks of three 12-byte groups: commit chunk j of window s, then refill the registers with window s + 1
     // Reflect-101 along the rows (Source.cpp:525-529) never shows in this kernel: a chunk whose window reaches over the image's left
     // or right edge reads it from a STRIP -- a copy of its 128 + 2 PADA window columns with the mirrored pixels in place, written by
@@ -289,13 +294,15 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
             const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rimg, in ? off + 96u * k : off, 0, 0);
             raw.d[k][0] = t[0]; raw.d[k][1] = t[1]; raw.d[k][2] = t[2];
         }
-        if (QUIRK && j == 0 && tid < 96) {
+        if (QUIRK && j == 0) {
             // the row term of row re of V (= image row refl(re - PADA)): dr (-1)^pad Srow, rounded once as the term kernels of rounds 2-3 did
-            const int c = tid >> 5, re = min(32 * s + (tid & 31), qrows - 1);
+            // (threads 0 .. 95 = (channel, row); the others repeat channel 2: no lane mask, see FxCfg)
+            const int c = min(tid >> 5, 2), re = min(32 * s + (tid & 31), qrows - 1);
             const int* sp = qk.srow_part + (static_cast<size_t>(f) * qk.nbatches * g.rows + mx_refl(re - PADA, g.rows)) * 3 + c;
-            int v = 0;
-            for (int b = 0; b < qk.nbatches; ++b) v += sp[static_cast<size_t>(b) * g.rows * 3];
-            qraw = static_cast<float>(qrs * v);
+            // the row's batch parts (at most kFxMaxBatches: fx_prepass widens its batches for wide images): independent loads, no
+            // loop with a wait inside -- they are added up when the term is committed, a step later
+#pragma unroll
+            for (int b = 0; b < kFxMaxBatches; ++b) qpart[b] = sp[static_cast<size_t>(min(b, qk.nbatches - 1)) * g.rows * 3];
         }
     };
     // one (group k, channel c) of the window: two v_perm_b32 (deinterleave + the low byte of a binary16 each) and one ds_write_b64
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #endif
         const int row = srow, g0 = tid & 7;
         if (k >= PER) return;
-        if ((C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8) {
+        {   // (groups past the window's GPR of the last k hold whatever their clamped load returned: they land in the row's padding)
             _Float16* base = reinterpret_cast<_Float16*>(fx_lds + buf * C::BUF) + row * PW + 4 * g0;
             // window pixels (0, 1) and (2, 3) of the group: bytes (c, 3 + c) and (6 + c, 9 + c)
             auto pick = [&](int B0, int B1) __attribute__((always_inline)) {
@@ -328,10 +335,14 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
         }
     };
     auto commit_q = [&](int buf) __attribute__((always_inline)) {
-        if (QUIRK && tid < 96) {
-            float* qs = reinterpret_cast<float*>(fx_lds + C::QOFF) + buf * 192 + tid;
+        if (QUIRK) {
+            int v = qpart[0];
+#pragma unroll
+            for (int b = 1; b < kFxMaxBatches; ++b) v += b < qk.nbatches ? qpart[b] : 0;
+            const float qraw = static_cast<float>(qrs * v);
+            float* qs = reinterpret_cast<float*>(fx_lds + C::QOFF) + buf * 512 + tid;
             qs[0] = qraw;            // the term enters as qrow (-1)^x: lanes of even x read this copy,
-            qs[96] = -qraw;          // lanes of odd x this one
+            qs[256] = -qraw;         // lanes of odd x this one
         }
     };
     auto commit_chunk = [&](int buf, int j) __attribute__((always_inline)) {
@@ -342,7 +353,16 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     // R: 32 rows x 32 pixels of channel c of the window in buffer `buf` -> arow
     // `beside(kb)` runs between the products of window block kb and kb + 1: the phase's vector work is handed out in slices, and a
     // scheduling fence after every block keeps the slices where they are (a window read is in flight for three blocks)
-    auto rowpass = [&](int buf, int c, auto beside) __attribute__((always_inline)) {
+    // (FX_XPRE: the first three window blocks of a row pass whose window is already complete -- channels 1 and 2 -- are requested
+    // from the tail of the phase B before it, so the pass does not open with an exposed LDS round trip)
+    mx_half8 xpre[3];
+    auto prefetch_x = [&](int buf, int c) __attribute__((always_inline)) {
+        const _Float16* base = reinterpret_cast<const _Float16*>(fx_lds + buf * C::BUF) + (c * 32 + m) * PW + wave * 32 + 8 * h;
+#pragma unroll
+        for (int kb = 0; kb < 3 && kb < NKB; ++kb) xpre[kb] = *reinterpret_cast<const mx_half8*>(base + 16 * kb);
+    };
+    (void)prefetch_x;
+    auto rowpass = [&](int buf, int c, auto beside, bool pre = false) __attribute__((always_inline)) {
         const _Float16* base = reinterpret_cast<const _Float16*>(fx_lds + buf * C::BUF) + (c * 32 + m) * PW + wave * 32 + 8 * h;
         mx_float16 a = zero;
         mx_half8 x[4];
@@ -350,7 +370,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #ifdef FX_ABL_NOXREAD
         for (int kb = 0; kb < 4; ++kb) x[kb] = th[kb];
 #else
-        for (int kb = 0; kb < 3 && kb < NKB; ++kb) x[kb] = *reinterpret_cast<const mx_half8*>(base + 16 * kb);
+        for (int kb = 0; kb < 3 && kb < NKB; ++kb) x[kb] = pre ? xpre[kb] : *reinterpret_cast<const mx_half8*>(base + 16 * kb);
 #endif
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -392,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #endif
         if (sub == 0) {
             if (QUIRK) {
-                const float* qs4 = reinterpret_cast<const float*>(fx_lds + C::QOFF) + buf * 192 + (m & 1) * 96 + c * 32 + 4 * h;
+                const float* qs4 = reinterpret_cast<const float*>(fx_lds + C::QOFF) + buf * 512 + (m & 1) * 256 + c * 32 + 4 * h;
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const float4 t4 = *reinterpret_cast<const float4*>(qs4 + 8 * (2 * hf + k));
@@ -577,13 +597,14 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
                             if (kb == 2) { split_piece(cur, c, 3); split_piece(cur, c, 5); }
                             if (kb == 3) split_piece(cur, c, 6);
                             if (kb == 4) split_piece(cur, c, 7);
+                            if (c == 0 && kb >= 5 && kb <= 8) store_group(s - 1 - NT, tvalid, kb - 5);
 #ifdef FX_NO_BALANCE
                             if (kb >= 2) commit_item(cbuf, 3 * jc + (kb - 2) / 3, (kb - 2) % 3);
-                            if (c == 0 && kb >= 5 && kb <= 8) store_group(s - 1 - NT, tvalid, kb - 5);
                             if (kb == NKB - 1) { if (jc == 0) commit_q(cbuf); issue_chunk(snext, jc); }
 #else
-                            // (the staging and the stores ride in phase B: A's two products per block leave room for the hand-off only)
-                            (void)tvalid; (void)jc; (void)cbuf; (void)snext;
+                            // (the staging rides in phase B: beside A's two products per block there is room for the hand-off, and in
+                            // A(s, 0) for the stores, but not for nine staging items on top)
+                            (void)jc; (void)cbuf; (void)snext;
 #endif
                         } else {
                             if (kb == 0) { split_piece(cur, c, 1); split_piece(cur, c, 2); split_piece(cur, c, 3); split_piece(cur, c, 5); split_piece(cur, c, 6); split_piece(cur, c, 7); }
@@ -593,7 +614,11 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
                             if (c == 0 && kb == NKB - 1) store_tile(s - 1 - NT, tvalid);
                         }
                     };
+#ifdef FX_XPRE
+                    if (c == 2) rowpass(cur ^ 1, 0, beside); else rowpass(cur, c + 1, beside, NKB >= 11 && (c == 1 || s > s0));
+#else
                     if (c == 2) rowpass(cur ^ 1, 0, beside); else rowpass(cur, c + 1, beside);
+#endif
                 }
 #ifndef FX_NOSB
                 __builtin_amdgcn_sched_barrier(0);
@@ -612,8 +637,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #ifndef FX_NO_BALANCE
                             // B has three products per slot and less to do beside them than A: the staging chunk of this product
                             // (c == 2: chunk 0 of window s + 2 -> buffer cur, which the barrier before A(s, 2) freed; c == 0, 1: chunk
-                            // c + 1 of window s + 1 -> buffer cur ^ 1, complete before that barrier) in slots 0, 7 .. 10, its re-issue
-                            // last; the stores of the tile this step finishes (all three channels emitted by slot 6 of c == 2) in 7 .. 10
+                            // c + 1 of window s + 1 -> buffer cur ^ 1, complete before that barrier) in slots 0, 7 .. 10, its re-issue last
                             {
                                 const int jc = c == 2 ? 0 : c + 1, cbuf = c == 2 ? cur : cur ^ 1, snext = c == 2 ? s + 3 : s + 2;
                                 const int sl = it == 0 ? 0 : it - 6;                       // 0, 1 .. 4
@@ -621,9 +645,12 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
                                     commit_item(cbuf, 3 * jc + (2 * sl) / 3, (2 * sl) % 3);
                                     if (sl < 4) commit_item(cbuf, 3 * jc + (2 * sl + 1) / 3, (2 * sl + 1) % 3);
                                 }
-                                if (c == 2 && it >= 7) store_group(s - NT, s - NT >= tile0, it - 7);
                                 if (it == NKB - 1) { if (jc == 0) commit_q(cbuf); issue_chunk(snext, jc); }
                             }
+#endif
+#ifdef FX_XPRE
+                            if (it == NKB - 2 && c == 0) prefetch_x(cur, 2);                 // A(s, 1): window s, channel 2
+                            if (it == NKB - 2 && c == 2) prefetch_x(cur ^ 1, 1);             // A(s + 1, 0): window s + 1, channel 1
 #endif
                         } else {
                             if (it == (NKB >= 5 ? 1 : 0)) { split_piece(nbuf, nc, 0, c == 2 ? s + 1 : s); split_piece(nbuf, nc, 4, c == 2 ? s + 1 : s); }
@@ -642,10 +669,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
             }
         }
     }
-    if (NKB < 11) store_tile(s1 - 1 - NT, s1 - 1 - NT >= tile0);
-#ifdef FX_NO_BALANCE
-    else store_tile(s1 - 1 - NT, s1 - 1 - NT >= tile0);          // (otherwise step s1 - 1 stored it in its last phase B)
-#endif
+    store_tile(s1 - 1 - NT, s1 - 1 - NT >= tile0);
 #ifdef FX_STAMPS
     if (!QUIRK && !DUMPV && vdump && blockIdx.x == 0 && tid == 0) {        // (timing-only build: vdump carries the stamp buffer)
         unsigned long long* o = reinterpret_cast<unsigned long long*>(vdump);
@@ -734,10 +758,19 @@ constexpr int kFxSumRows = 32;          // image rows per sub-band (packed 16-bi
 // rows per workgroup of the pre-pass: sub-bands of 32 (16 for small frames: twice the workgroups, each half as long).  Every band
 // leaves a part of the column sums that every fused workgroup adds up for its own columns: tall bands where the batch still gives
 // four workgroups per CU
+// groups of 4 pixels per thread and row of the pre-pass: batches of 1024 gpt pixel columns, at most kFxMaxBatches of them (0: too wide)
+inline int fx_groups_per_thread(int cols)
+{
+    const int groups = cols / 4;
+    for (int g = 1; g <= 4; g *= 2)
+        if (groups <= 256 * g * kFxMaxBatches) return g;
+    return 0;
+}
 inline int fx_band_rows(int rows, int cols, int nframes, int num_cus)
 {
     if (static_cast<long long>(rows) * cols < 4000000ll) return 16;
-    const long long nbatches = (cols / 4 + 255) / 256;
+    const int gpt = fx_groups_per_thread(cols);
+    const long long nbatches = (cols / 4 + 256 * gpt - 1) / (256 * (gpt > 0 ? gpt : 1));
     int br = kFxSumRows;
     while (br < 128 && nbatches * ((rows + 2 * br - 1) / (2 * br)) * nframes >= 4ll * num_cus) br *= 2;
     return br;
@@ -752,88 +785,109 @@ inline int fx_band_rows(int rows, int cols, int nframes, int num_cus)
 // an 8 x 4K batch cost the pre-pass 16 us, more than the consumers' few extra loads.)
 // sred[row][channel][lane]: lane l of every wave adds into slot l (one conflict-free ds_add_u32 per value: a same-address atomic the
 // compiler would turn into a serial loop over the lanes, and a DPP reduction costs twelve dependent instructions)
+// G = groups per thread and row (1, 2, 4): a batch is 256 G groups wide, so that an image of up to 4096 G pixel columns has at most
+// kFxMaxBatches batches (the fused kernel adds a row's batch parts up with that many unconditional loads)
+template <int G>
 __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
                                                 int rows, int cols, int pad, int nbands, int nbatches, int band, int batch, int f, int (*sred)[3][64], int band_rows)
 {
     const int tid = threadIdx.x;
     const uint8_t* img = src + static_cast<size_t>(f) * rows * cols * 3;
     const int groups = cols / 4, r0 = band * band_rows, r1 = min(r0 + band_rows, rows);
-    const int gi = batch * 256 + tid, x = 4 * gi;
-    const bool act = gi < groups;
     const int flip = (pad & 1) ? -1 : 1;
-    const bool plain = x > pad && x + 3 < cols - 1 - pad;                 // no pixel of the group is mirrored: weights +-1 by parity
-    int wq[4];
+    int gi[G], wq[G][4];
+    bool act[G], plain[G];
+    const uint8_t* col0[G];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) wq[q] = act ? mx_alt_weight(x + q, cols, pad) : 0;
-    int o[12];                                                            // the band's column sums of the thread's 12 bytes
+    for (int j = 0; j < G; ++j) {
+        gi[j] = (batch * G + j) * 256 + tid;
+        const int x = 4 * gi[j];
+        act[j] = gi[j] < groups;
+        plain[j] = x > pad && x + 3 < cols - 1 - pad;                     // no pixel of the group is mirrored: weights +-1 by parity
 #pragma unroll
-    for (int j = 0; j < 12; ++j) o[j] = 0;
+        for (int q = 0; q < 4; ++q) wq[j][q] = act[j] ? mx_alt_weight(x + q, cols, pad) : 0;
+        col0[j] = img + 12 * static_cast<size_t>(act[j] ? gi[j] : 0);
+    }
+    int o[G][12];                                                         // the band's column sums of the thread's bytes
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+#pragma unroll
+        for (int k = 0; k < 12; ++k) o[j][k] = 0;
     long long zacc = 0;                                                   // threads 0 .. 95 = (row of the sub-band, channel)
     typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-    const uint8_t* col0 = img + 12 * static_cast<size_t>(act ? gi : 0);
     for (int rs = r0; rs < r1; rs += kFxSumRows) {
         const int re = min(rs + kFxSumRows, r1);
         for (int i = tid; i < kFxSumRows * 3 * 64; i += 256) (&sred[0][0][0])[i] = 0;
         __syncthreads();
-        uint32_t accp[6], accn[6];                                        // packed 16-bit sums of the rows with positive / negative wy
+        uint32_t accp[G][6], accn[G][6];                                  // packed 16-bit sums of the rows with positive / negative wy
 #pragma unroll
-        for (int j = 0; j < 6; ++j) accp[j] = accn[j] = 0;
-        for (int rb = rs; rb < re; rb += 8) {
-            u3 d[8];
+        for (int j = 0; j < G; ++j)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int k = 0; k < 6; ++k) accp[j][k] = accn[j][k] = 0;
+        constexpr int RB = G == 1 ? 8 : (G == 2 ? 4 : 2);                 // rows of loads in flight (RB G loads of 12 bytes per thread)
+        for (int rb = rs; rb < re; rb += RB) {
+            u3 d[RB][G];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
                 const int r = min(rb + i, re - 1);
-                d[i] = *reinterpret_cast<const u3*>(col0 + static_cast<size_t>(r) * cols * 3);
+#pragma unroll
+                for (int j = 0; j < G; ++j) d[i][j] = *reinterpret_cast<const u3*>(col0[j] + static_cast<size_t>(r) * cols * 3);
             }
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
+            for (int i = 0; i < RB; ++i) {
                 const int r = rb + i;
                 if (r < re) {                                                    // uniform
                     const int wy = mx_alt_weight(r, rows, pad);
-                    int s[3] = { 0, 0, 0 };
-                    if (plain) {
-                        const int e0 = static_cast<int>(d[i][0] ^ 0x80808080u), e1 = static_cast<int>(d[i][1] ^ 0x80808080u), e2 = static_cast<int>(d[i][2] ^ 0x80808080u);
-                        // bytes (pixel q, channel c) = 3 q + c of the group, signs + - + - over q; the offset 128 cancels (weights sum to 0)
-                        int t0 = __builtin_amdgcn_sdot4(e0, static_cast<int>(0xff000001u), 0, false);
-                        t0 = __builtin_amdgcn_sdot4(e1, 0x00010000, t0, false);
-                        t0 = __builtin_amdgcn_sdot4(e2, 0x0000ff00, t0, false);
-                        int t1 = __builtin_amdgcn_sdot4(e0, 0x00000100, 0, false);
-                        t1 = __builtin_amdgcn_sdot4(e1, 0x010000ff, t1, false);
-                        t1 = __builtin_amdgcn_sdot4(e2, 0x00ff0000, t1, false);
-                        int t2 = __builtin_amdgcn_sdot4(e0, 0x00010000, 0, false);
-                        t2 = __builtin_amdgcn_sdot4(e1, 0x0000ff00, t2, false);
-                        t2 = __builtin_amdgcn_sdot4(e2, static_cast<int>(0xff000001u), t2, false);
-                        s[0] = flip * t0; s[1] = flip * t1; s[2] = flip * t2;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-#pragma unroll
-                            for (int c = 0; c < 3; ++c) {
-                                const int byte = 3 * q + c;
-                                s[c] += wq[q] * static_cast<int>((d[i][byte >> 2] >> (8 * (byte & 3))) & 0xffu);
-                            }
-                    }
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) atomicAdd(&sred[r - rs][c][tid & 63], act ? s[c] : 0);
-                    // column sums: bytes 0, 2 of each dword in one packed pair, bytes 1, 3 in the other; |wy| = 1, 2 or 3 (uniform)
                     const uint32_t aw = static_cast<uint32_t>(wy < 0 ? -wy : wy);
+                    int s[3] = { 0, 0, 0 };
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        uint32_t lo = __builtin_amdgcn_perm(0u, d[i][j], 0x0c020c00u), hi = __builtin_amdgcn_perm(0u, d[i][j], 0x0c030c01u);     // bytes 0, 2 | 1, 3
-                        if (aw != 1) { lo *= aw; hi *= aw; }                      // (uniform: the mirrored rows only)
-                        if (wy > 0) { accp[2 * j] += lo; accp[2 * j + 1] += hi; }
-                        else { accn[2 * j] += lo; accn[2 * j + 1] += hi; }
+                    for (int j = 0; j < G; ++j) {
+                        const u3 dd = d[i][j];
+                        if (plain[j]) {
+                            const int e0 = static_cast<int>(dd[0] ^ 0x80808080u), e1 = static_cast<int>(dd[1] ^ 0x80808080u), e2 = static_cast<int>(dd[2] ^ 0x80808080u);
+                            // bytes (pixel q, channel c) = 3 q + c of the group, signs + - + - over q; the offset 128 cancels (weights sum to 0)
+                            int t0 = __builtin_amdgcn_sdot4(e0, static_cast<int>(0xff000001u), 0, false);
+                            t0 = __builtin_amdgcn_sdot4(e1, 0x00010000, t0, false);
+                            t0 = __builtin_amdgcn_sdot4(e2, 0x0000ff00, t0, false);
+                            int t1 = __builtin_amdgcn_sdot4(e0, 0x00000100, 0, false);
+                            t1 = __builtin_amdgcn_sdot4(e1, 0x010000ff, t1, false);
+                            t1 = __builtin_amdgcn_sdot4(e2, 0x00ff0000, t1, false);
+                            int t2 = __builtin_amdgcn_sdot4(e0, 0x00010000, 0, false);
+                            t2 = __builtin_amdgcn_sdot4(e1, 0x0000ff00, t2, false);
+                            t2 = __builtin_amdgcn_sdot4(e2, static_cast<int>(0xff000001u), t2, false);
+                            s[0] += flip * t0; s[1] += flip * t1; s[2] += flip * t2;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int c = 0; c < 3; ++c) {
+                                    const int byte = 3 * q + c;
+                                    s[c] += wq[j][q] * static_cast<int>((dd[byte >> 2] >> (8 * (byte & 3))) & 0xffu);
+                                }
+                        }
+                        // column sums: bytes 0, 2 of each dword in one packed pair, bytes 1, 3 in the other; |wy| = 1, 2 or 3 (uniform)
+#pragma unroll
+                        for (int k = 0; k < 3; ++k) {
+                            uint32_t lo = __builtin_amdgcn_perm(0u, dd[k], 0x0c020c00u), hi = __builtin_amdgcn_perm(0u, dd[k], 0x0c030c01u);     // bytes 0, 2 | 1, 3
+                            if (aw != 1) { lo *= aw; hi *= aw; }                  // (uniform: the mirrored rows only)
+                            if (wy > 0) { accp[j][2 * k] += lo; accp[j][2 * k + 1] += hi; }
+                            else { accn[j][2 * k] += lo; accn[j][2 * k + 1] += hi; }
+                        }
                     }
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) atomicAdd(&sred[r - rs][c][tid & 63], s[c]);      // (groups right of the image: not `plain`, weights 0)
                 }
             }
         }
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            o[4 * j] += static_cast<int>(accp[2 * j] & 0xffffu) - static_cast<int>(accn[2 * j] & 0xffffu);
-            o[4 * j + 2] += static_cast<int>(accp[2 * j] >> 16) - static_cast<int>(accn[2 * j] >> 16);
-            o[4 * j + 1] += static_cast<int>(accp[2 * j + 1] & 0xffffu) - static_cast<int>(accn[2 * j + 1] & 0xffffu);
-            o[4 * j + 3] += static_cast<int>(accp[2 * j + 1] >> 16) - static_cast<int>(accn[2 * j + 1] >> 16);
-        }
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                o[j][4 * k] += static_cast<int>(accp[j][2 * k] & 0xffffu) - static_cast<int>(accn[j][2 * k] & 0xffffu);
+                o[j][4 * k + 2] += static_cast<int>(accp[j][2 * k] >> 16) - static_cast<int>(accn[j][2 * k] >> 16);
+                o[j][4 * k + 1] += static_cast<int>(accp[j][2 * k + 1] & 0xffffu) - static_cast<int>(accn[j][2 * k + 1] & 0xffffu);
+                o[j][4 * k + 3] += static_cast<int>(accp[j][2 * k + 1] >> 16) - static_cast<int>(accn[j][2 * k + 1] >> 16);
+            }
         __syncthreads();
         if (tid < (re - rs) * 3) {
             const int* p64 = &sred[0][0][0] + 64 * tid;
@@ -845,12 +899,14 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
         }
         __syncthreads();                                                   // sred is zeroed again / reused below
     }
-    if (act) {
-        int4* dstp = reinterpret_cast<int4*>(cpart + (static_cast<size_t>(f) * nbands + band) * (3 * cols) + 12 * gi);
-        dstp[0] = make_int4(o[0], o[1], o[2], o[3]);
-        dstp[1] = make_int4(o[4], o[5], o[6], o[7]);
-        dstp[2] = make_int4(o[8], o[9], o[10], o[11]);
-    }
+#pragma unroll
+    for (int j = 0; j < G; ++j)
+        if (act[j]) {
+            int4* dstp = reinterpret_cast<int4*>(cpart + (static_cast<size_t>(f) * nbands + band) * (3 * cols) + 12 * gi[j]);
+            dstp[0] = make_int4(o[j][0], o[j][1], o[j][2], o[j][3]);
+            dstp[1] = make_int4(o[j][4], o[j][5], o[j][6], o[j][7]);
+            dstp[2] = make_int4(o[j][8], o[j][9], o[j][10], o[j][11]);
+        }
     long long* zs = reinterpret_cast<long long*>(&sred[0][0][0]);          // (the last sub-band's barrier has passed: sred is free)
     if (tid < 96) zs[tid] = zacc;
     __syncthreads();
@@ -865,13 +921,15 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
 // none with nyquist_quirk = 0) and the edge strips (strip_blocks x nstrips x frames workgroups, last in the grid: they fill the tail)
 __global__ __launch_bounds__(256) void fx_prepass(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
                                                   uint8_t* __restrict__ strips, int rows, int cols, int pad, int pada, int nbands, int nbatches, int n_alt, int chunks,
-                                                  int nright, int strip_blocks, int band_rows)
+                                                  int nright, int strip_blocks, int band_rows, int gpt)
 {
     __shared__ int sred[kFxSumRows][3][64];
     int b = blockIdx.x;
     if (b < n_alt) {
         const int band = b % nbands, batch = (b / nbands) % nbatches, f = b / (nbands * nbatches);
-        fx_altsums_body(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
+        if (gpt == 1) fx_altsums_body<1>(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
+        else if (gpt == 2) fx_altsums_body<2>(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
+        else fx_altsums_body<4>(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
     } else {
         b -= n_alt;
         const int nstrips = fx_left_strips(pada) + nright, bx = b % strip_blocks, sidx = (b / strip_blocks) % nstrips, f = b / (strip_blocks * nstrips);
