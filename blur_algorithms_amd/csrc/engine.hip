@@ -1675,8 +1675,8 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     FxQuirk qk{};
     if (!p.mx_quirk) {
         TimedLaunch t(ctx, 1, nframes);
-        hipLaunchKernelGGL(fx_prepass, dim3(n_strip), dim3(256), 0, ctx->stream, d_src, nullptr, nullptr, nullptr, ctx->fx_strips, rows, cols, p.sz.pad, pada, 1, 1, 0, chunks_x,
-                           g.nright, strip_blocks, kFxSumRows, 1);
+        hipLaunchKernelGGL(fx_prepass<1>, dim3(n_strip), dim3(256), 0, ctx->stream, d_src, nullptr, nullptr, nullptr, ctx->fx_strips, rows, cols, p.sz.pad, pada, 1, 1, 0, chunks_x,
+                           g.nright, strip_blocks, kFxSumRows);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (p.mx_quirk) {
@@ -1698,8 +1698,9 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         long long* zpart = reinterpret_cast<long long*>(cpart + n_cpart);
         { TimedLaunch t(ctx, 1, nframes);
           const int n_alt = nbands * nbatches * nframes;
-          hipLaunchKernelGGL(fx_prepass, dim3(n_alt + n_strip), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, ctx->fx_strips, rows, cols, p.sz.pad, pada, nbands,
-                             nbatches, n_alt, chunks_x, g.nright, strip_blocks, band_rows, gpt);
+          auto kern = gpt == 1 ? fx_prepass<1> : (gpt == 2 ? fx_prepass<2> : fx_prepass<4>);
+          hipLaunchKernelGGL(kern, dim3(n_alt + n_strip), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, ctx->fx_strips, rows, cols, p.sz.pad, pada, nbands,
+                             nbatches, n_alt, chunks_x, g.nright, strip_blocks, band_rows);
           HIP_TRY(ctx, hipGetLastError()); }
         qk.srow_part = srow;
         qk.cpart = cpart;

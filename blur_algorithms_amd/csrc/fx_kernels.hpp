@@ -353,16 +353,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     // R: 32 rows x 32 pixels of channel c of the window in buffer `buf` -> arow
     // `beside(kb)` runs between the products of window block kb and kb + 1: the phase's vector work is handed out in slices, and a
     // scheduling fence after every block keeps the slices where they are (a window read is in flight for three blocks)
-    // (FX_XPRE: the first three window blocks of a row pass whose window is already complete -- channels 1 and 2 -- are requested
-    // from the tail of the phase B before it, so the pass does not open with an exposed LDS round trip)
-    mx_half8 xpre[3];
-    auto prefetch_x = [&](int buf, int c) __attribute__((always_inline)) {
-        const _Float16* base = reinterpret_cast<const _Float16*>(fx_lds + buf * C::BUF) + (c * 32 + m) * PW + wave * 32 + 8 * h;
-#pragma unroll
-        for (int kb = 0; kb < 3 && kb < NKB; ++kb) xpre[kb] = *reinterpret_cast<const mx_half8*>(base + 16 * kb);
-    };
-    (void)prefetch_x;
-    auto rowpass = [&](int buf, int c, auto beside, bool pre = false) __attribute__((always_inline)) {
+    auto rowpass = [&](int buf, int c, auto beside) __attribute__((always_inline)) {
         const _Float16* base = reinterpret_cast<const _Float16*>(fx_lds + buf * C::BUF) + (c * 32 + m) * PW + wave * 32 + 8 * h;
         mx_float16 a = zero;
         mx_half8 x[4];
@@ -370,7 +361,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #ifdef FX_ABL_NOXREAD
         for (int kb = 0; kb < 4; ++kb) x[kb] = th[kb];
 #else
-        for (int kb = 0; kb < 3 && kb < NKB; ++kb) x[kb] = pre ? xpre[kb] : *reinterpret_cast<const mx_half8*>(base + 16 * kb);
+        for (int kb = 0; kb < 3 && kb < NKB; ++kb) x[kb] = *reinterpret_cast<const mx_half8*>(base + 16 * kb);
 #endif
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb) {
@@ -614,11 +605,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
                             if (c == 0 && kb == NKB - 1) store_tile(s - 1 - NT, tvalid);
                         }
                     };
-#ifdef FX_XPRE
-                    if (c == 2) rowpass(cur ^ 1, 0, beside); else rowpass(cur, c + 1, beside, NKB >= 11 && (c == 1 || s > s0));
-#else
                     if (c == 2) rowpass(cur ^ 1, 0, beside); else rowpass(cur, c + 1, beside);
-#endif
                 }
 #ifndef FX_NOSB
                 __builtin_amdgcn_sched_barrier(0);
@@ -647,10 +634,6 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
                                 }
                                 if (it == NKB - 1) { if (jc == 0) commit_q(cbuf); issue_chunk(snext, jc); }
                             }
-#endif
-#ifdef FX_XPRE
-                            if (it == NKB - 2 && c == 0) prefetch_x(cur, 2);                 // A(s, 1): window s, channel 2
-                            if (it == NKB - 2 && c == 2) prefetch_x(cur ^ 1, 1);             // A(s + 1, 0): window s + 1, channel 1
 #endif
                         } else {
                             if (it == (NKB >= 5 ? 1 : 0)) { split_piece(nbuf, nc, 0, c == 2 ? s + 1 : s); split_piece(nbuf, nc, 4, c == 2 ? s + 1 : s); }
@@ -892,7 +875,7 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
         if (tid < (re - rs) * 3) {
             const int* p64 = &sred[0][0][0] + 64 * tid;
             int v = 0;
-#pragma unroll
+#pragma unroll 8
             for (int k = 0; k < 64; ++k) v += p64[(k + tid) & 63];              // (rotated: the 96 threads start on different banks)
             srow_part[((static_cast<size_t>(f) * nbatches + batch) * rows + rs) * 3 + tid] = v;
             zacc += static_cast<long long>(mx_alt_weight(rs + tid / 3, rows, pad)) * v;
@@ -918,18 +901,18 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
 }
 
 // One launch for everything that has to happen before the fused kernel: the quirk's sums (n_alt = bands x batches x frames workgroups,
-// none with nyquist_quirk = 0) and the edge strips (strip_blocks x nstrips x frames workgroups, last in the grid: they fill the tail)
+// none with nyquist_quirk = 0) and the edge strips (strip_blocks x nstrips x frames workgroups, last in the grid: they fill the tail).
+// One kernel per G (groups per thread of the sums): the wide forms need three times the registers of G = 1
+template <int G>
 __global__ __launch_bounds__(256) void fx_prepass(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
                                                   uint8_t* __restrict__ strips, int rows, int cols, int pad, int pada, int nbands, int nbatches, int n_alt, int chunks,
-                                                  int nright, int strip_blocks, int band_rows, int gpt)
+                                                  int nright, int strip_blocks, int band_rows)
 {
     __shared__ int sred[kFxSumRows][3][64];
     int b = blockIdx.x;
     if (b < n_alt) {
         const int band = b % nbands, batch = (b / nbands) % nbatches, f = b / (nbands * nbatches);
-        if (gpt == 1) fx_altsums_body<1>(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
-        else if (gpt == 2) fx_altsums_body<2>(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
-        else fx_altsums_body<4>(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
+        fx_altsums_body<G>(src, srow_part, cpart, zpart, rows, cols, pad, nbands, nbatches, band, batch, f, sred, band_rows);
     } else {
         b -= n_alt;
         const int nstrips = fx_left_strips(pada) + nright, bx = b % strip_blocks, sidx = (b / strip_blocks) % nstrips, f = b / (strip_blocks * nstrips);
