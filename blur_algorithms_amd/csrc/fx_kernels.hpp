@@ -131,24 +131,45 @@ __device__ __forceinline__ void fx_quirk_cols_tile(unsigned char* scratch, float
     double* tp = cc + nval;
     double* zs = tp + ntap;
     const size_t bstride = static_cast<size_t>(3) * cols;
-    for (int i = tid; i < nval; i += 256) {
-        const int p = i / NCH, ch = NCH == 3 ? i - 3 * p : c0;
-        const int* cp = q.cpart + static_cast<size_t>(f) * q.nbands * bstride + 3 * mx_refl(x0 - pad + p, cols) + ch;
-        int sum[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        int b = 0;
-        for (; b + 8 <= q.nbands; b += 8) {
+    {   // the tile: thread t owns values t + 256 v; the bands' parts in groups of BG, all NV x BG loads of a group in flight together
+        // (a loop of dependent waits costs one trip to L2 / the Infinity Cache per band: 1-2 us each at one wave per SIMD)
+        constexpr int NVMAX = NCH == 3 ? 4 : 2, BG = NCH == 3 ? 12 : 24;
+        const int* cp[NVMAX];
+        int sum[NVMAX];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum[j] += cp[(b + j) * bstride];
+        for (int v = 0; v < NVMAX; ++v) {
+            const int i = min(tid + 256 * v, nval - 1), p = i / NCH, ch = NCH == 3 ? i - 3 * p : c0;
+            cp[v] = q.cpart + static_cast<size_t>(f) * q.nbands * bstride + 3 * mx_refl(x0 - pad + p, cols) + ch;
+            sum[v] = 0;
         }
-        for (; b < q.nbands; ++b) sum[0] += cp[b * bstride];
-        cc[i] = static_cast<double>(((sum[0] + sum[1]) + (sum[2] + sum[3])) + ((sum[4] + sum[5]) + (sum[6] + sum[7])));
+        for (int b0 = 0; b0 < q.nbands; b0 += BG) {
+            int t[NVMAX][BG];
+#pragma unroll
+            for (int j = 0; j < BG; ++j)
+#pragma unroll
+                for (int v = 0; v < NVMAX; ++v) t[v][j] = cp[v][static_cast<size_t>(min(b0 + j, q.nbands - 1)) * bstride];
+#pragma unroll
+            for (int j = 0; j < BG; ++j)
+#pragma unroll
+                for (int v = 0; v < NVMAX; ++v) sum[v] += b0 + j < q.nbands ? t[v][j] : 0;
+        }
+#pragma unroll
+        for (int v = 0; v < NVMAX; ++v)
+            if (tid + 256 * v < nval) cc[tid + 256 * v] = static_cast<double>(sum[v]);
     }
     for (int i = tid; i < ntap; i += 256) tp[i] = static_cast<double>(q.taps[i]);
-    {   // Z: wave w < 3 adds up channel w's parts (exact integers), a lane per part, then across the wave
+    {   // Z: wave w < 3 adds up channel w's parts (exact integers), four independent loads per lane and trip, then across the wave
         const int w = tid >> 6, l = tid & 63, nz = q.nbands * q.nbatches;
         if (w < 3 && (NCH == 3 || w == c0)) {
+            const long long* zp = q.zpart + static_cast<size_t>(f) * nz * 3 + w;
             long long z = 0;
-            for (int i = l; i < nz; i += 64) z += q.zpart[(static_cast<size_t>(f) * nz + i) * 3 + w];
+            for (int i0 = l; i0 < nz; i0 += 256) {
+                long long t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) t[j] = zp[static_cast<size_t>(min(i0 + 64 * j, nz - 1)) * 3];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) z += i0 + 64 * j < nz ? t[j] : 0;
+            }
             for (int o = 32; o >= 1; o >>= 1) z += __shfl_xor(z, o, 64);
             if (l == 0) zs[w] = static_cast<double>(z);
         }
