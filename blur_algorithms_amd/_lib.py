@@ -40,6 +40,7 @@ SYMBOLS = {
     "blur_ctx_set_stream": (C.c_int, [_P, _P]),
     "blur_ctx_synchronize": (C.c_int, [_P]),
     "blur_last_error": (C.c_char_p, [_P]),
+    "blur_last_engine": (C.c_int, [_P, C.c_char_p, C.c_size_t]),
     "blur_ctx_timing_enable": (C.c_int, [_P, C.c_int]),
     "blur_ctx_timing": (C.c_int, [_P, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     "blur_gaussian_u8c3_dev": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_double, C.POINTER(BlurOpts)]),

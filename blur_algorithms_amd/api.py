@@ -162,6 +162,13 @@ class BlurContext:
         fn.restype = C.c_int
         return int(fn(self._h))
 
+    def last_engine(self):
+        """(family code, note): the kernels the last u8c3 blur ran on and, under the library's own choice, why a faster engine was
+        passed over (blur_last_engine)"""
+        buf = C.create_string_buffer(512)
+        fam = int(self._lib.blur_last_engine(self._h, buf, 512))
+        return fam, buf.value.decode()
+
     def copy_bandwidth(self, mib=1024, reps=5):
         """GB/s (read + written) of a 16-byte-per-lane device copy of `mib` MiB: the box's streaming rate for the kernels' access shape"""
         g = C.c_double(0)

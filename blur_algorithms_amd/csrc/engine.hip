@@ -677,6 +677,7 @@ struct blur_ctx {
     size_t work2_bytes = 0;
     uint8_t* box_tmp = nullptr;
     size_t box_bytes = 0;
+    std::string engine_note;      // BLUR_ENGINE_AUTO: why the last call's choice passed over a faster engine ("" if it did not)
     int last_family = -1;         // kernels the last u8c3 blur used: 0 run-time plans, 1 specialised rows-first, 2 wave-resident, 3 whole-image 2D, 4 matrix-core (two kernels), 6 fused matrix-core
     void* host_stage = nullptr;   // device staging of the host-pointer entry points (kept between calls: no allocation per frame)
     size_t host_stage_bytes = 0;
@@ -1117,12 +1118,33 @@ static int mx_get_tables(blur_ctx* ctx, int nkb, double sigma, const Sizing& sz,
     return BLUR_OK;
 }
 
-// ptrs_aligned: the frame pointers of the call are 4-byte aligned (a condition of the fused kernel)
-// BLUR_FUSED_WIDE=1 (developer switch): the library's own choice includes the wide fused kernels
-static bool fused_wide_auto()
+// ptrs_aligned: the frame pointers of the call are 4-byte aligned (no engine depends on it any more: the fused kernels take any
+// width and alignment since round 4)
+// The one rule both the matrix-core branch and the FFT branch of prepare() consult: do the wave-resident FFT kernels pay for this
+// frame?  Both passes need a kernel (N = 256 R0 >= line + 2 pad) whose LDS holds the image; where the rows-first family has
+// compile-time kernels for BOTH reference lengths as well (the six BASELINE (length, role) pairs) the wave-resident pair must fill
+// its waves (R0 >= 8 / 12, lines at least 3/4 of N), elsewhere it competes with the run-time-planned kernels and wins as soon as the
+// lines are at least half of N.  (Measured, us per frame wave-resident / rows-first: 4K sigma 20 106 / 107; 1080p sigma 20 41 / 36;
+// 1000 x 1500 sigma 38.7 32 / 144; 1300 x 1950 sigma 44 83 / 87.)
+struct FftFamilyChoice {
+    const WrEntry* wc = nullptr;       // wave-resident column kernel / row kernel, where they exist and fit
+    const WrEntry* wr = nullptr;
+    bool fits = false;                 // both exist and their LDS holds the image
+    bool old_both = false;             // the rows-first family has compile-time kernels for both reference lengths
+    bool wr_pays = false;
+};
+static FftFamilyChoice fft_family_choice(int rows, int cols, const Sizing& sz)
 {
-    static const bool on = [] { const char* e = getenv("BLUR_FUSED_WIDE"); return e && *e && *e != '0'; }();
-    return on;
+    FftFamilyChoice c;
+    c.wc = find_wr_entry(rows + 2 * sz.pad, true);
+    c.wr = find_wr_entry(cols + 2 * sz.pad, false);
+    c.old_both = find_fast_entry(sz.n_col, true) && find_fast_entry(sz.n_row, false);
+    c.fits = c.wc && c.wr && c.wc->col_lds(rows) <= kLdsLimit && c.wr->row_lds(cols) <= kLdsLimit;
+    if (c.fits) {
+        const int need_c = rows + 2 * sz.pad, need_r = cols + 2 * sz.pad, nc = c.wc->r0 * kWrS, nr = c.wr->r0 * kWrS;
+        c.wr_pays = c.old_both ? (c.wc->r0 >= 8 && c.wr->r0 >= 12 && 4 * need_c >= 3 * nc && 4 * need_r >= 3 * nr) : (2 * need_c >= nc && 2 * need_r >= nr);
+    }
+    return c;
 }
 
 static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p, bool u8c3 = true,
@@ -1131,6 +1153,7 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     if (!ctx) return BLUR_ERR_INVALID;
     if (rows <= 0 || cols <= 0 || (!ck && !(sigma > 0))) return fail(ctx, BLUR_ERR_INVALID, "rows, cols and sigma must be positive");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->engine_note.clear();
     if (ck) {
         p.sz = Sizing{};
         p.sz.kSize = ck->box_klen > 0 ? ck->box_klen : ck->ksize;
@@ -1147,8 +1170,8 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     const bool allow_fast = u8c3 && !(opts && opts->force_generic == 1);   // force the generic kernels (tests)
     // Engine choice (enum blur_engine).  The library's own policy, BLUR_ENGINE_AUTO, in the order it is applied:
     //   | engine                      | where                                                   | measured (MI355X, 8 frames per call)            |
-    //   | fused matrix-core kernel    | pad <= 72 (sigma <~ 22), cols % 4 == 0, aligned frames,  | 4K sigma 20: 47 us per frame against 70 for the  |
-    //   |                             | non-negative taps with sum <= 1                         | two kernels and 105 for the FFT kernels          |
+    //   | fused matrix-core kernel    | pad <= 72 (sigma <~ 22), non-negative taps with sum <= 1 | 4K sigma 20: 45 us per frame against 70 for the  |
+    //   |                             | (any width, any pointer alignment)                      | two kernels and 105 for the FFT kernels          |
     //   | fused kernel, wide windows  | pad 73 .. 168 on frames >= 6 MP (not where the next row | 4K sigma 30: 98 GP/s against 85 / 70; 8K sigma 40 |
     //   |                             | applies), same conditions                               | single frame 79 against 54 / 26                   |
     //   | FFT, compile-time families  | frames < 1 MP, or pad > 136 on frames >= 6 MP           | 1080p sigma 20 single frame 72 / 78 us;          |
@@ -1175,15 +1198,8 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         // FASTER on the matrix cores than on the wave-resident FFT kernels, so the rule is limited to large frames)
         const bool small = static_cast<long long>(rows) * cols < 1000000ll, wide = me0 && me0->nkb >= 19 && static_cast<long long>(rows) * cols >= 6000000ll;
         if (small || wide) {
-            const WrEntry* wc = find_wr_entry(rows + 2 * p.sz.pad, true);
-            const WrEntry* wr = find_wr_entry(cols + 2 * p.sz.pad, false);
-            const bool old_both = find_fast_entry(p.sz.n_col, true) && find_fast_entry(p.sz.n_row, false);
-            bool wr_pays = false;
-            if (wc && wr && wc->col_lds(rows) <= kLdsLimit && wr->row_lds(cols) <= kLdsLimit) {
-                const int need_c = rows + 2 * p.sz.pad, need_r = cols + 2 * p.sz.pad, nc = wc->r0 * kWrS, nr = wr->r0 * kWrS;
-                wr_pays = old_both ? (wc->r0 >= 8 && wr->r0 >= 12 && 4 * need_c >= 3 * nc && 4 * need_r >= 3 * nr) : (2 * need_c >= nc && 2 * need_r >= nr);
-            }
-            small_fft = wr_pays || old_both;
+            const FftFamilyChoice fc = fft_family_choice(rows, cols, p.sz);
+            small_fft = fc.wr_pays || fc.old_both;
         }
     }
     if (allow_fast && allow_wr && (choice == BLUR_ENGINE_FUSED || choice == BLUR_ENGINE_AUTO)) {
@@ -1193,17 +1209,18 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         // 1080p sigma 30 single 29 / 31 / 36, eight 68 / 63 / 59; 1000 x 1500 sigma 38.7 single 17 / 21 / 13; 4K sigma 50 single
         // 39 / 37 / 57, eight 68-73 / 63 / 63-74, sigma 44 eight 76 / 63 / 64): the library's own choice for frames of 6 MP and more,
         // except the widest window (23 blocks, pad > 152) where the FFT engine has a compile-time family for the frame (small_fft
-        // above).  BLUR_FUSED_WIDE=1: always.
-        if (fe && fe->nkb > 11 && choice == BLUR_ENGINE_AUTO && !fused_wide_auto() &&
-            (static_cast<long long>(rows) * cols < 6000000ll || (small_fft && fe->nkb >= 23))) fe = nullptr;
+        // above).
         const char* why = nullptr;
-        if (!fe) why = "fused matrix-core engine: no kernel instantiated for this pad";
+        if (fe && fe->nkb > 11 && choice == BLUR_ENGINE_AUTO) {
+            if (static_cast<long long>(rows) * cols < 6000000ll) { fe = nullptr; why = "wide fused kernel (pad 73 .. 168): frames below 6 MP run faster on two kernels"; }
+            else if (small_fft && fe->nkb >= 23) { fe = nullptr; why = "wide fused kernel: pad > 152 where the FFT engine has a compile-time family for the frame"; }
+        }
+        if (!fe && !why) why = "fused matrix-core engine: no kernel instantiated for this pad";
         // (0xfffffff0 is the offset the kernels give a dropped store: it must lie outside the frame's buffer resource)
         else if (static_cast<long long>(rows) * cols * 3 > 0xfffffff0ll) why = "fused matrix-core engine: frame too large for 32-bit offsets";
-        else if ((cols & 3) != 0) why = "fused matrix-core engine: the image width must be a multiple of 4";
         else if (quirk && fx_groups_per_thread(cols) == 0) why = "fused matrix-core engine: image wider than 16384 pixels (the quirk's pre-pass)";
-        else if (!ptrs_aligned) why = "fused matrix-core engine: frame pointers must be 4-byte aligned";
         if (why && choice == BLUR_ENGINE_FUSED) return fail(ctx, BLUR_ERR_UNSUPPORTED, why);
+        if (why) ctx->engine_note = why;
         if (!why) {
             const int rc = mx_get_tables(ctx, fe->nkb, sigma, p.sz, ck, &p.mxt, choice == BLUR_ENGINE_AUTO);
             if (rc != BLUR_OK && choice == BLUR_ENGINE_FUSED) return rc;
@@ -1234,20 +1251,12 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     }
     // Wave-resident kernels first (reserved[3] = 1 switches them off): both passes need one, and its LDS must hold the image
     if (allow_fast && allow_wr && !(opts && opts->engine == BLUR_ENGINE_FFT_ROWS_FIRST)) {
-        const WrEntry* wc = find_wr_entry(rows + 2 * p.sz.pad, true);
-        const WrEntry* wr = find_wr_entry(cols + 2 * p.sz.pad, false);
-        // Default policy (reserved[3] = 2: wherever the image fits).  Measured on MI355X, us per frame, wave-resident against
-        // rows-first: 4K sigma 20 106 / 107 (both families specialised: equal; the wave-resident pair writes whole sectors
-        // only, HBM traffic 1.00x algorithmic); 1080p sigma 20 41 / 36 (5 x 256 columns fill 5 of 16 wave slots);
-        // 1000 x 1500 sigma 38.7 32 / 144 and 1300 x 1950 sigma 44 83 / 87 (no specialised rows-first kernel: run-time plans).
-        bool pays = opts && opts->engine == BLUR_ENGINE_FFT_WAVE_RESIDENT;
-        if (!pays && wc && wr) {
-            const int need_c = rows + 2 * p.sz.pad, need_r = cols + 2 * p.sz.pad, nc = wc->r0 * kWrS, nr = wr->r0 * kWrS;
-            const bool old_both = find_fast_entry(p.sz.n_col, true) && find_fast_entry(p.sz.n_row, false);
-            if (old_both) pays = wc->r0 >= 8 && wr->r0 >= 12 && 4 * need_c >= 3 * nc && 4 * need_r >= 3 * nr;   // full waves in both kernels
-            else pays = 2 * need_c >= nc && 2 * need_r >= nr;
-        }
-        if (wc && wr && pays && wc->col_lds(rows) <= kLdsLimit && wr->row_lds(cols) <= kLdsLimit &&
+        // (BLUR_ENGINE_FFT_WAVE_RESIDENT: wherever the image fits; otherwise the rule of fft_family_choice)
+        const FftFamilyChoice fc = fft_family_choice(rows, cols, p.sz);
+        const WrEntry* wc = fc.wc;
+        const WrEntry* wr = fc.wr;
+        const bool pays = (opts && opts->engine == BLUR_ENGINE_FFT_WAVE_RESIDENT) || fc.wr_pays;
+        if (fc.fits && pays &&
             wr_frame_floats(rows, cols, p.sz.pad) / 3 < (static_cast<size_t>(1) << 30)) {
             if (int rc = wr_get_tables(ctx, wc, &p.wr_tw0_col)) return rc;
             if (int rc = wr_get_tables(ctx, wr, &p.wr_tw0_row)) return rc;
@@ -1660,7 +1669,6 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     const int nkb = p.fx->nkb, pada = 8 * (nkb - 2);
     FxGeom g{ rows, cols, p.sz.pad, nframes, 0, (rows + 31) / 32, fx_right_strips(cols, pada), ctx->num_xcds };
     g.aligned = ((cols & 3) == 0 && (reinterpret_cast<uintptr_t>(d_src) & 3) == 0 && (reinterpret_cast<uintptr_t>(d_dst) & 3) == 0) ? 1 : 0;
-    if (!g.aligned) return fail(ctx, BLUR_ERR_UNSUPPORTED, "fused matrix-core engine: frame pointers must be 4-byte aligned");
     {   // the edge chunks' windows
         const int win = kFxChunk + 2 * pada, nstrips = fx_left_strips(pada) + g.nright;
         const size_t bytes = static_cast<size_t>(nframes) * nstrips * rows * win * 3 + 64;
@@ -1683,9 +1691,10 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         // the quirk's partial sums (exact integers): srow_part [frame][batch][row][3], cpart [frame][band][3 cols], zpart (64-bit)
         // [frame][band][batch][3]; the fused kernel adds them up where it needs them (struct FxQuirk)
         const int gpt = fx_groups_per_thread(cols);
-        const int band_rows = fx_band_rows(rows, cols, nframes, ctx->num_cus), nbands = (rows + band_rows - 1) / band_rows, nbatches = (cols / 4 + 256 * gpt - 1) / (256 * gpt);
+        const int groups = (cols + 3) / 4;
+        const int band_rows = fx_band_rows(rows, cols, nframes, ctx->num_cus), nbands = (rows + band_rows - 1) / band_rows, nbatches = (groups + 256 * gpt - 1) / (256 * gpt);
         auto up4 = [](size_t v) { return (v + 3) & ~static_cast<size_t>(3); };
-        const size_t n_srow = up4(static_cast<size_t>(nframes) * nbatches * rows * 3), n_cpart = up4(static_cast<size_t>(nframes) * nbands * 3 * cols);
+        const size_t n_srow = up4(static_cast<size_t>(nframes) * nbatches * rows * 3), n_cpart = up4(static_cast<size_t>(nframes) * nbands * 12 * groups);
         const size_t n_z = static_cast<size_t>(nframes) * nbands * nbatches * 3;
         const size_t bytes = (n_srow + n_cpart) * sizeof(int) + n_z * sizeof(long long) + 64;
         if (ctx->fx_sums_bytes < bytes) {
@@ -1708,6 +1717,7 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
         qk.taps = p.mxt->taps_row;
         qk.nbatches = nbatches;
         qk.nbands = nbands;
+        qk.cpitch = 12 * groups;
         qk.dr = p.mxt->dr;
         qk.dc = p.mxt->dc;
     }
@@ -2431,6 +2441,19 @@ int blur_wr_length(int need, int column_role)
 // 2 wave-resident, 3 whole-image 2D transform, 4 two-kernel matrix-core engine, 6 fused matrix-core kernel; -1 none yet
 // (bench.py --preset reference-sweep reports it per size)
 int blur_debug_last_family(const blur_ctx* ctx) { return ctx ? ctx->last_family : -1; }
+
+int blur_last_engine(const blur_ctx* ctx, char* note, size_t n)
+{
+    if (!ctx) return -1;
+    static const char* const names[] = { "run-time-planned FFT kernels", "specialised rows-first FFT kernels", "wave-resident FFT kernels", "whole-image 2D FFT",
+                                         "two-kernel matrix-core engine", "?", "fused matrix-core kernel" };
+    if (note && n > 0) {
+        std::string t = ctx->last_family >= 0 && ctx->last_family <= 6 ? names[ctx->last_family] : "none yet";
+        if (!ctx->engine_note.empty()) t += " (not taken: " + ctx->engine_note + ")";
+        std::snprintf(note, n, "%s", t.c_str());
+    }
+    return ctx->last_family;
+}
 
 // redzone tests: number of bytes of the workspace's two guard bands that were overwritten (0 = intact; -1 = no workspace yet)
 int blur_debug_check_workspace_guards(blur_ctx* ctx)

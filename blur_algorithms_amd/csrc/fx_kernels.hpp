@@ -46,7 +46,8 @@ namespace blur_amd {
 struct FxGeom {
     int rows, cols, pad;
     int nframes;
-    int aligned;      // 1: cols % 4 == 0 and frame pointers 4-byte aligned: 12-byte pixel groups are three aligned dwords
+    int aligned;      // 1: cols % 4 == 0 and frame pointers 4-byte aligned: 12-byte pixel groups are three aligned dwords (informational: the
+                      // kernels take any width and alignment; unaligned 12-byte accesses are what the memory pipeline then sees)
     int ntiles;       // output tiles of 32 rows per frame
     int nright;       // chunks at the right edge that read their window from a strip (the chunk at the left edge always does)
     int nxcd;         // XCDs of the device (hipDeviceAttributeNumberOfXccs): workgroup b runs on XCD b % nxcd
@@ -116,6 +117,7 @@ struct FxQuirk {
     const long long* zpart;     // [frame][band][batch][3]   parts of Z(c) = sum_r wy(r) Srow(r, c)
     const float* taps;          // the 2 pad + 1 taps of the row pass, centre at pad
     int nbatches, nbands;
+    int cpitch;                 // ints per band row of cpart: 12 x groups of 4 pixels (>= 3 cols)
     float dr, dc;
 };
 
@@ -130,7 +132,7 @@ __device__ __forceinline__ void fx_quirk_cols_tile(unsigned char* scratch, float
     double* cc = reinterpret_cast<double*>(scratch);
     double* tp = cc + nval;
     double* zs = tp + ntap;
-    const size_t bstride = static_cast<size_t>(3) * cols;
+    const size_t bstride = static_cast<size_t>(q.cpitch);
     {   // the tile: thread t owns values t + 256 v; the bands' parts in groups of BG, all NV x BG loads of a group in flight together
         // (a loop of dependent waits costs one trip to L2 / the Infinity Cache per band: 1-2 us each at one wave per SIMD)
         constexpr int NVMAX = NCH == 3 ? 4 : 2, BG = NCH == 3 ? 12 : 24;
@@ -212,7 +214,9 @@ __device__ __forceinline__ void fx_quirk_cols_tile(unsigned char* scratch, float
 // by S(n+1) early in B(n), before R(n+2) writes it again.
 // DUMPV (tests only, blur_rowpass_u8c3_dev with BLUR_ENGINE_FUSED): the row pass's float planes V' (quirk term included), as the
 // hand-off reads them, also go to vdump[frame][channel][row][col] -- what the reference holds in `resf` after Source.cpp:520-537.
-template <int NKB, bool QUIRK, bool DUMPV = false>
+// RAGGED: the image width is not a multiple of 4: the last quad of 4 pixels of a row holds 1 .. 3 of them and leaves as single bytes
+// (nine more store instructions per row group, with an offset outside the buffer for every lane that has nothing to store)
+template <int NKB, bool QUIRK, bool DUMPV = false, bool RAGGED = false>
 __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, const mx_half8* __restrict__ frags, FxGeom g,
                                                      int chunks, int tps, int nseg, int ntasks, FxQuirk qk, const uint8_t* __restrict__ strips,
                                                      float* __restrict__ vdump)
@@ -247,7 +251,8 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     const uint32_t sel1 = (lane & 1) ? 0x03070105u : 0x06020400u, sel2 = (lane & 2) ? 0x03020706u : 0x05040100u;
     const int Q = m >> 2, q = m & 3;
     const int xpix = x0 + 32 * wave + 4 * Q;                       // first of the lane's 4 pixels after the transposes
-    const bool in_cols = xpix < g.cols;
+    const bool in_cols = xpix + 3 < g.cols;                        // the whole quad lies inside the image: one 12-byte store
+    const int tail_bytes = RAGGED && !in_cols && xpix < g.cols ? 3 * (g.cols - xpix) : 0;       // 3, 6 or 9 bytes of a quad cut by the right edge
     float cpos[3], cneg[3];
     if (QUIRK) {
         // the column term of this chunk's pixels (nothing else uses LDS yet: tile and taps in window buffer 0, the result in buffer 1)
@@ -547,6 +552,14 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
             const bool ok = valid && in_cols && 32 * tile + 8 * gq + 4 * h + q < g.rows;
 #endif
             __builtin_amdgcn_raw_buffer_store_b96(w, rout, ok ? lane_out + rowoff : 0xfffffff0u, 0, 0);
+            if (RAGGED) {
+                const bool rok = valid && 32 * tile + 8 * gq + 4 * h + q < g.rows;
+#pragma unroll
+                for (int b = 0; b < 9; ++b) {
+                    const uint32_t word = b < 4 ? w0 : (b < 8 ? w1 : w2);
+                    __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(word >> (8 * (b & 3))), rout, (rok && b < tail_bytes) ? lane_out + rowoff + b : 0xfffffff0u, 0, 0);
+                }
+            }
         }
     };
     auto store_tile = [&](int tile, bool valid) __attribute__((always_inline)) {
@@ -705,9 +718,9 @@ inline int fx_right_strips(int cols, int pada)
 }
 
 // strips[f][strip][row][p][3], p = 0 .. 128 + 2 pada - 1: pixel refl101(x0 - pada + p) of the row, x0 = 128 xc of the strip's chunk
-// (beyond one reflection, which only zero taps read: whatever the clamped load returns).  A thread moves one group of 4 pixels: the
-// image width is a multiple of 4 and so is x0 - pada, so a group lies inside the image (one aligned 12-byte load) or is the
-// pixel-reversed copy of 4 adjacent image pixels (one unaligned 12-byte load, three v_perm_b32).
+// (beyond one reflection, which only zero taps read: whatever the clamped load returns).  A thread moves one group of 4 pixels: it
+// lies inside the image (one 12-byte load), is the pixel-reversed copy of 4 adjacent image pixels (one 12-byte load, three
+// v_perm_b32), or -- image widths that are not multiples of 4, tiny images -- straddles an edge and is gathered pixel by pixel.
 // work items (fx_prepass): blocks over ceil(rows / 4) x win / 4 threads (4 rows of one group each) x strips x frames
 __device__ __forceinline__ void fx_edge_strips_body(const uint8_t* __restrict__ src, uint8_t* __restrict__ strips, int rows, int cols, int pada, int chunks, int nright,
                                                     int bx, int sidx, int f)
@@ -765,7 +778,7 @@ constexpr int kFxSumRows = 32;          // image rows per sub-band (packed 16-bi
 // groups of 4 pixels per thread and row of the pre-pass: batches of 1024 gpt pixel columns, at most kFxMaxBatches of them (0: too wide)
 inline int fx_groups_per_thread(int cols)
 {
-    const int groups = cols / 4;
+    const int groups = (cols + 3) / 4;
     for (int g = 1; g <= 4; g *= 2)
         if (groups <= 256 * g * kFxMaxBatches) return g;
     return 0;
@@ -774,16 +787,17 @@ inline int fx_band_rows(int rows, int cols, int nframes, int num_cus)
 {
     if (static_cast<long long>(rows) * cols < 4000000ll) return 16;
     const int gpt = fx_groups_per_thread(cols);
-    const long long nbatches = (cols / 4 + 256 * gpt - 1) / (256 * (gpt > 0 ? gpt : 1));
+    const long long nbatches = ((cols + 3) / 4 + 256 * gpt - 1) / (256 * (gpt > 0 ? gpt : 1));
     int br = kFxSumRows;
     while (br < 128 && nbatches * ((rows + 2 * br - 1) / (2 * br)) * nframes >= 4ll * num_cus) br *= 2;
     return br;
 }
 
 // workgroup (band of band_rows rows, batch of 256 twelve-byte groups = 1024 pixel columns, frame), 256 threads: a thread owns one
-// group (4 pixels) of every row of the band, eight rows of loads in flight; cols % 4 == 0, frames 4-byte aligned.  Exact integers:
+// group (4 pixels) of every row of the band, eight rows of loads in flight; any width (the last group of a row may hold 1 .. 3 pixels)
+// and any alignment (12-byte loads at byte addresses).  Exact integers:
 //   srow_part[f][batch][r][c]  sum over the batch's pixels of wx(x) img[r][x][c]
-//   cpart[f][band][3 x + c]    sum over the band's rows of wy(r) img[r][x][c]
+//   cpart[f][band][3 x + c]    sum over the band's rows of wy(r) img[r][x][c]          (band rows 12 x groups ints apart)
 //   zpart[f][band][batch][c]   sum over the band's rows of wy(r) srow_part[f][batch][r][c]       (the parts of Z)
 // (Adding the parts up with atomics instead -- Srow and Ccol complete when the launch ends -- was measured: the 3 M atomic adds of
 // an 8 x 4K batch cost the pre-pass 16 us, more than the consumers' few extra loads.)
@@ -797,11 +811,14 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
 {
     const int tid = threadIdx.x;
     const uint8_t* img = src + static_cast<size_t>(f) * rows * cols * 3;
-    const int groups = cols / 4, r0 = band * band_rows, r1 = min(r0 + band_rows, rows);
+    // (a buffer resource per frame: the last group of a row whose width is not a multiple of 4 reaches into the next row -- weights 0 --
+    // and, in the last row, past the frame: those bytes read as 0 instead of touching memory that is not the caller's)
+    const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, static_cast<uint32_t>(rows) * cols * 3u, kMxRsrcWord3);
+    const int groups = (cols + 3) / 4, r0 = band * band_rows, r1 = min(r0 + band_rows, rows);
     const int flip = (pad & 1) ? -1 : 1;
     int gi[G], wq[G][4];
     bool act[G], plain[G];
-    const uint8_t* col0[G];
+    uint32_t col0[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
         gi[j] = (batch * G + j) * 256 + tid;
@@ -809,8 +826,8 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
         act[j] = gi[j] < groups;
         plain[j] = x > pad && x + 3 < cols - 1 - pad;                     // no pixel of the group is mirrored: weights +-1 by parity
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wq[j][q] = act[j] ? mx_alt_weight(x + q, cols, pad) : 0;
-        col0[j] = img + 12 * static_cast<size_t>(act[j] ? gi[j] : 0);
+        for (int q = 0; q < 4; ++q) wq[j][q] = (act[j] && x + q < cols) ? mx_alt_weight(x + q, cols, pad) : 0;
+        col0[j] = 12u * static_cast<uint32_t>(act[j] ? gi[j] : 0);
     }
     int o[G][12];                                                         // the band's column sums of the thread's bytes
 #pragma unroll
@@ -835,7 +852,7 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
             for (int i = 0; i < RB; ++i) {
                 const int r = min(rb + i, re - 1);
 #pragma unroll
-                for (int j = 0; j < G; ++j) d[i][j] = *reinterpret_cast<const u3*>(col0[j] + static_cast<size_t>(r) * cols * 3);
+                for (int j = 0; j < G; ++j) d[i][j] = __builtin_amdgcn_raw_buffer_load_b96(rimg, col0[j] + static_cast<uint32_t>(r) * static_cast<uint32_t>(cols) * 3u, 0, 0);
             }
 #pragma unroll
             for (int i = 0; i < RB; ++i) {
@@ -906,7 +923,7 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
 #pragma unroll
     for (int j = 0; j < G; ++j)
         if (act[j]) {
-            int4* dstp = reinterpret_cast<int4*>(cpart + (static_cast<size_t>(f) * nbands + band) * (3 * cols) + 12 * gi[j]);
+            int4* dstp = reinterpret_cast<int4*>(cpart + (static_cast<size_t>(f) * nbands + band) * (12 * static_cast<size_t>(groups)) + 12 * gi[j]);
             dstp[0] = make_int4(o[j][0], o[j][1], o[j][2], o[j][3]);
             dstp[1] = make_int4(o[j][4], o[j][5], o[j][6], o[j][7]);
             dstp[2] = make_int4(o[j][8], o[j][9], o[j][10], o[j][11]);
@@ -989,19 +1006,24 @@ template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, u
     static std::atomic<unsigned long long> attr_done{ 0 };
     int dev;
     if (fx_attr_needed(attr_done, dev)) {
-        const void* kernels[4] = { reinterpret_cast<const void*>(fx_blur_u8<NKB, true, false>), reinterpret_cast<const void*>(fx_blur_u8<NKB, false, false>),
-                                   reinterpret_cast<const void*>(fx_blur_u8<NKB, true, true>), reinterpret_cast<const void*>(fx_blur_u8<NKB, false, true>) };
+        const void* kernels[6] = { reinterpret_cast<const void*>(fx_blur_u8<NKB, true, false>), reinterpret_cast<const void*>(fx_blur_u8<NKB, false, false>),
+                                   reinterpret_cast<const void*>(fx_blur_u8<NKB, true, true>), reinterpret_cast<const void*>(fx_blur_u8<NKB, false, true>),
+                                   reinterpret_cast<const void*>(fx_blur_u8<NKB, true, false, true>), reinterpret_cast<const void*>(fx_blur_u8<NKB, false, false, true>) };
         for (const void* k : kernels) {
             const hipError_t e = hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
             if (e != hipSuccess) return e;
         }
         fx_attr_mark(attr_done, dev);
     }
-#define FX_LAUNCH(Q_, D_)                                                                                                                                  \
-    hipLaunchKernelGGL((fx_blur_u8<NKB, Q_, D_>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg,     \
+#define FX_LAUNCH(Q_, D_, R_)                                                                                                                              \
+    hipLaunchKernelGGL((fx_blur_u8<NKB, Q_, D_, R_>), grid, dim3(256), C::LDS, st, src, dst, static_cast<const mx_half8*>(frags), g, chunks, tps, nseg, \
                        static_cast<int>(ntasks), qk ? *qk : FxQuirk{}, strips, vdump ? vdump : reinterpret_cast<float*>(stamps))
-    if (vdump) { if (qk) FX_LAUNCH(true, true); else FX_LAUNCH(false, true); }
-    else { if (qk) FX_LAUNCH(true, false); else FX_LAUNCH(false, false); }
+    const bool ragged = (g.cols & 3) != 0;
+    if (vdump) {
+        if (ragged) return hipErrorNotSupported;                 // (the row-pass dump is a test instantiation: whole quads only)
+        if (qk) FX_LAUNCH(true, true, false); else FX_LAUNCH(false, true, false);
+    } else if (ragged) { if (qk) FX_LAUNCH(true, false, true); else FX_LAUNCH(false, false, true); }
+    else { if (qk) FX_LAUNCH(true, false, false); else FX_LAUNCH(false, false, false); }
 #undef FX_LAUNCH
     return hipGetLastError();
 }

@@ -42,10 +42,11 @@ typedef struct blur_ctx blur_ctx;
    about speed and about what each engine can hold.  engine.hip: prepare() holds the policy table of BLUR_ENGINE_AUTO. */
 enum blur_engine {
     BLUR_ENGINE_AUTO = 0,            /* fused matrix-core kernel where it exists for the kernel's half width (pad <= 72; pad <= 168
-                                        on frames of 6 MP and more), the image width is a multiple of 4 and the frame pointers
-                                        are 4-byte aligned; else the two-kernel matrix-core engine (pad <= 168, non-negative
-                                        taps) except where the FFT engine has a faster compile-time family (small frames, the
-                                        widest kernels on 4K frames); else FFT */
+                                        on frames of 6 MP and more; any image width, any pointer alignment); else the two-kernel
+                                        matrix-core engine (pad <= 168, non-negative taps) except where the FFT engine has a faster
+                                        compile-time family (small frames, the widest kernels on 4K frames); else FFT.  The choice
+                                        depends on rows, cols and the kernel only: never on the number of frames, on where the
+                                        frames lie in memory or on the environment (blur_last_engine() names it) */
     BLUR_ENGINE_FFT_ROWS_FIRST = 1,  /* FFT kernels, never the wave-resident family */
     BLUR_ENGINE_FFT_WAVE_RESIDENT = 2, /* FFT kernels, wave-resident (transform length 256 R0, columns first) wherever the image fits */
     BLUR_ENGINE_MATRIX = 3,          /* two-kernel matrix-core engine (mx_kernels.hpp); BLUR_ERR_UNSUPPORTED if it cannot hold the kernel */
@@ -118,6 +119,11 @@ int blur_ctx_synchronize(blur_ctx* ctx);
 /* message of the last failing call on this ctx ("" if none); ctx may be NULL for
    failures of blur_ctx_create */
 const char* blur_last_error(const blur_ctx* ctx);
+/* which kernels the last u8c3 blur on this ctx ran on: returns 0 run-time-planned FFT, 1 specialised rows-first FFT, 2 wave-resident
+   FFT, 3 whole-image 2D FFT, 4 two-kernel matrix-core engine, 6 fused matrix-core kernel (-1: none yet), and writes into note
+   (n bytes, may be NULL) the engine's name and, under BLUR_ENGINE_AUTO, why a faster engine was passed over -- e.g.
+   "two-kernel matrix-core engine (not taken: wide fused kernel (pad 73 .. 168): frames below 6 MP run faster on two kernels)" */
+int blur_last_engine(const blur_ctx* ctx, char* note, size_t n);
 
 /* Per-kernel timing with HIP events on the ctx's stream.  While enabled, every launch
    of the row-pass and column-pass kernels is bracketed by events; blur_ctx_timing()

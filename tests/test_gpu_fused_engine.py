@@ -21,7 +21,7 @@ def _fam(ctx):
     return ctx.last_family()
 
 
-# widths are multiples of 4 (a condition of the kernel); heights are anything; below one chunk of 128 columns, exactly one,
+# widths that are multiples of 4 (the others: RAGGED below); heights are anything; below one chunk of 128 columns, exactly one,
 # several with a ragged last one; heights below one tile of 32 rows (pad + 1 at least), ragged last tiles
 SHAPES = [(270, 480, 20.0), (200, 332, 20.0), (131, 152, 18.0), (540, 960, 21.5), (97, 644, 19.0), (1080, 1920, 20.0), (70, 68, 20.0), (100, 100, 20.0),
           (67, 256, 19.0), (300, 72, 20.0), (66, 132, 20.0)]
@@ -174,30 +174,76 @@ def test_fused_engine_extreme_images(ctx):
 
 
 def test_where_the_fused_kernel_does_not_apply(ctx):
-    """an image width that is no multiple of 4, an unaligned frame pointer, a kernel wider than 337 taps: asking for the fused
-    kernel is an error, the library's own choice takes another engine and gives the oracle's bytes"""
+    """a kernel wider than 337 taps: asking for the fused kernel is an error, the library's own choice takes another engine and gives
+    the oracle's bytes (widths that are no multiples of 4 and unaligned frame pointers ARE the fused kernel's since round 4: below)"""
     from blur_algorithms_amd.api import BlurError
     from oracle import oracle as O
     torch = _torch()
-    img = _rand_img(210, 333, 5)
+    img = _rand_img(400, 400, 7)
     with pytest.raises(BlurError):
-        ctx.pffft_(torch.from_numpy(img).cuda(), 20.0, engine="fused")
-    want, planes = O.pffft_blur_u8c3_f64(img, 20.0, quirk=True, want_planes=True)
-    got = ctx.pffft_(torch.from_numpy(img).cuda(), 20.0).cpu().numpy()
+        ctx.pffft_(torch.from_numpy(img).cuda(), 55.0, engine="fused")          # pad 182 > 168
+    want, planes = O.pffft_blur_u8c3_f64(img, 55.0, quirk=True, want_planes=True)
+    got = ctx.pffft_(torch.from_numpy(img).cuda(), 55.0).cpu().numpy()
     assert _fam(ctx) != 6
     assert_u8_parity(got, want, planes)
-    img4 = _rand_img(210, 332, 6)
-    with pytest.raises(BlurError):
-        ctx.pffft_(torch.from_numpy(_rand_img(400, 400, 7)).cuda(), 55.0, engine="fused")          # pad 182 > 168
-    buf = torch.zeros(img4.size + 16, dtype=torch.uint8, device="cuda")
-    off = buf[2:2 + img4.size].view(210, 332, 3)
-    off.copy_(torch.from_numpy(img4))
-    with pytest.raises(BlurError):
-        ctx.pffft_(off, 20.0, out=torch.empty_like(torch.from_numpy(img4).cuda()), engine="fused")
-    want, planes = O.pffft_blur_u8c3_f64(img4, 20.0, quirk=True, want_planes=True)
-    got = ctx.pffft_(off, 20.0, out=torch.empty_like(torch.from_numpy(img4).cuda())).cpu().numpy()
-    assert _fam(ctx) != 6
+
+
+# every residue of the width modulo 4 (the last quad of a row then holds 1 .. 3 pixels: pffft_() takes whatever cv::imread returns,
+# Source.cpp:459-461,567; the reference's own test image crop Baseline.jpg is 333 x 251), narrow and several chunks wide, both edges
+RAGGED = [(210, 333, 20.0), (251, 333, 20.0), (131, 154, 18.0), (97, 643, 19.0), (70, 69, 20.0), (66, 131, 20.0), (100, 257, 12.0), (150, 1026, 20.0), (80, 135, 5.0)]
+
+
+@pytest.mark.parametrize("rows,cols,sigma", RAGGED)
+@pytest.mark.parametrize("quirk", [False, True])
+def test_fused_engine_any_width(ctx, rows, cols, sigma, quirk):
+    from oracle import oracle as O
+    torch = _torch()
+    img = _rand_img(rows, cols, 7 * rows + cols)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=quirk, want_planes=True)
+    src = torch.from_numpy(img).cuda()
+    # guard bytes behind the output: the cut quad at the end of the last row must not write past the frame
+    buf = torch.full((img.size + 64,), 0xA5, dtype=torch.uint8, device="cuda")
+    out = buf[:img.size].view(rows, cols, 3)
+    got = ctx.pffft_(src, sigma, out=out, nyquist_quirk=quirk).cpu().numpy()
+    assert _fam(ctx) == 6
     assert_u8_parity(got, want, planes)
+    assert bool((buf[img.size:] == 0xA5).all())
+
+
+@pytest.mark.parametrize("off_in,off_out", [(1, 0), (2, 3), (3, 1), (0, 2)])
+@pytest.mark.parametrize("cols", [332, 333, 646])
+def test_fused_engine_any_alignment(ctx, off_in, off_out, cols):
+    """frame pointers at byte offsets 1, 2, 3 (a cv::Mat ROI, a tensor view): the same kernel, the same bytes as the aligned call"""
+    from oracle import oracle as O
+    torch = _torch()
+    rows, sigma = 140, 20.0
+    img = _rand_img(rows, cols, cols + off_in)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=True, want_planes=True)
+    ibuf = torch.full((img.size + 80,), 0x5A, dtype=torch.uint8, device="cuda")
+    obuf = torch.full((img.size + 80,), 0xA5, dtype=torch.uint8, device="cuda")
+    src = ibuf[16 + off_in:16 + off_in + img.size].view(rows, cols, 3)
+    dst = obuf[16 + off_out:16 + off_out + img.size].view(rows, cols, 3)
+    src.copy_(torch.from_numpy(img))
+    got = ctx.pffft_(src, sigma, out=dst).cpu().numpy()
+    assert _fam(ctx) == 6
+    assert_u8_parity(got, want, planes)
+    assert bool((obuf[:16 + off_out] == 0xA5).all()) and bool((obuf[16 + off_out + img.size:] == 0xA5).all())
+    aligned = ctx.pffft_(torch.from_numpy(img).cuda(), sigma).cpu().numpy()
+    assert np.array_equal(aligned, got)
+
+
+@pytest.mark.parametrize("rows,cols,sigma", [(300, 401, 25.0), (340, 131, 36.0), (400, 522, 50.0)])
+def test_wide_fused_kernels_any_width(ctx, rows, cols, sigma):
+    from oracle import oracle as O
+    torch = _torch()
+    img = _rand_img(rows, cols, rows + cols)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=True, want_planes=True)
+    buf = torch.full((img.size + 67,), 0xA5, dtype=torch.uint8, device="cuda")
+    out = buf[3:3 + img.size].view(rows, cols, 3)
+    got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma, out=out, engine="fused").cpu().numpy()
+    assert _fam(ctx) == 6
+    assert_u8_parity(got, want, planes)
+    assert bool((buf[:3] == 0xA5).all()) and bool((buf[3 + img.size:] == 0xA5).all())
 
 
 def test_fused_engine_metric_frame(ctx):
