@@ -126,6 +126,17 @@ class BlurContext:
 
     def _opts(self, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0, row_major_planes=False,
               wave_resident=None, engine=None):
+        # one blur_opts per distinct argument tuple, built once (a call on a small image is tens of microseconds of GPU time: the
+        # wrapper must not cost more than the kernels)
+        key = (bool(nyquist_quirk), int(col_group), bool(force_generic), int(frames_per_launch), bool(row_major_planes), wave_resident, engine)
+        cache = self.__dict__.setdefault("_opts_cache", {})
+        o = cache.get(key)
+        if o is not None:
+            return o
+        o = cache[key] = self._build_opts(*key)
+        return o
+
+    def _build_opts(self, nyquist_quirk, col_group, force_generic, frames_per_launch, row_major_planes, wave_resident, engine):
         o = BlurOpts()
         self._lib.blur_opts_default(C.byref(o))
         o.nyquist_quirk = 1 if nyquist_quirk else 0
@@ -145,11 +156,20 @@ class BlurContext:
         return o
 
     def use_torch_stream(self):
+        """launch on torch's current stream of this device (the raw handle: torch.cuda.current_stream() builds a Stream object per
+        call, several microseconds; the context is only told when the handle changed)"""
         import torch
-        self._check(self._lib.blur_ctx_set_stream(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
+        try:
+            h = torch._C._cuda_getCurrentRawStream(self.device)
+        except AttributeError:  # pragma: no cover - older / newer torch without the private accessor
+            h = torch.cuda.current_stream(self.device).cuda_stream
+        if h != self.__dict__.get("_stream_handle", -1):
+            self._check(self._lib.blur_ctx_set_stream(self._h, C.c_void_p(h)))
+            self._stream_handle = h
 
     def set_stream(self, handle):
         self._check(self._lib.blur_ctx_set_stream(self._h, C.c_void_p(handle)))
+        self._stream_handle = handle
 
     def synchronize(self):
         self._check(self._lib.blur_ctx_synchronize(self._h))

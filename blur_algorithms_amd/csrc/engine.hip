@@ -1219,6 +1219,7 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         // (0xfffffff0 is the offset the kernels give a dropped store: it must lie outside the frame's buffer resource)
         else if (static_cast<long long>(rows) * cols * 3 > 0xfffffff0ll) why = "fused matrix-core engine: frame too large for 32-bit offsets";
         else if (quirk && fx_groups_per_thread(cols) == 0) why = "fused matrix-core engine: image wider than 16384 pixels (the quirk's pre-pass)";
+        else if (quirk && cols < 4) why = "fused matrix-core engine: image narrower than 4 pixels (the quirk's pre-pass)";
         if (why && choice == BLUR_ENGINE_FUSED) return fail(ctx, BLUR_ERR_UNSUPPORTED, why);
         if (why) ctx->engine_note = why;
         if (!why) {

@@ -794,8 +794,8 @@ inline int fx_band_rows(int rows, int cols, int nframes, int num_cus)
 }
 
 // workgroup (band of band_rows rows, batch of 256 twelve-byte groups = 1024 pixel columns, frame), 256 threads: a thread owns one
-// group (4 pixels) of every row of the band, eight rows of loads in flight; any width (the last group of a row may hold 1 .. 3 pixels)
-// and any alignment (12-byte loads at byte addresses).  Exact integers:
+// group (4 pixels) of every row of the band, eight rows of loads in flight; any width >= 4 (the last group of a row then overlaps the
+// one before it) and any alignment (12-byte loads at byte addresses).  Exact integers:
 //   srow_part[f][batch][r][c]  sum over the batch's pixels of wx(x) img[r][x][c]
 //   cpart[f][band][3 x + c]    sum over the band's rows of wy(r) img[r][x][c]          (band rows 12 x groups ints apart)
 //   zpart[f][band][batch][c]   sum over the band's rows of wy(r) srow_part[f][batch][r][c]       (the parts of Z)
@@ -811,23 +811,26 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
 {
     const int tid = threadIdx.x;
     const uint8_t* img = src + static_cast<size_t>(f) * rows * cols * 3;
-    // (a buffer resource per frame: the last group of a row whose width is not a multiple of 4 reaches into the next row -- weights 0 --
-    // and, in the last row, past the frame: those bytes read as 0 instead of touching memory that is not the caller's)
+    // (a buffer resource per frame: 32-bit offsets, and nothing outside the frame can be touched)
     const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, static_cast<uint32_t>(rows) * cols * 3u, kMxRsrcWord3);
     const int groups = (cols + 3) / 4, r0 = band * band_rows, r1 = min(r0 + band_rows, rows);
     const int flip = (pad & 1) ? -1 : 1;
+    // a width that is no multiple of 4 (cols >= 4): the LAST group of a row is loaded from pixel cols - 4, overlapping the group before
+    // it by `over` pixels (weights 0 there, and its column sums are stored shifted by 3 over values), so that no load leaves the row
+    const int over = (4 - (cols & 3)) & 3;
     int gi[G], wq[G][4];
-    bool act[G], plain[G];
+    bool act[G], plain[G], last[G];
     uint32_t col0[G];
 #pragma unroll
     for (int j = 0; j < G; ++j) {
         gi[j] = (batch * G + j) * 256 + tid;
-        const int x = 4 * gi[j];
         act[j] = gi[j] < groups;
-        plain[j] = x > pad && x + 3 < cols - 1 - pad;                     // no pixel of the group is mirrored: weights +-1 by parity
+        last[j] = over != 0 && gi[j] == groups - 1;
+        const int x = 4 * gi[j] - (last[j] ? over : 0);
+        plain[j] = !last[j] && x > pad && x + 3 < cols - 1 - pad;         // no pixel of the group is mirrored: weights +-1 by parity
 #pragma unroll
-        for (int q = 0; q < 4; ++q) wq[j][q] = (act[j] && x + q < cols) ? mx_alt_weight(x + q, cols, pad) : 0;
-        col0[j] = 12u * static_cast<uint32_t>(act[j] ? gi[j] : 0);
+        for (int q = 0; q < 4; ++q) wq[j][q] = (act[j] && !(last[j] && q < over)) ? mx_alt_weight(x + q, cols, pad) : 0;
+        col0[j] = act[j] ? 3u * static_cast<uint32_t>(x) : 0u;
     }
     int o[G][12];                                                         // the band's column sums of the thread's bytes
 #pragma unroll
@@ -919,6 +922,15 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
             zacc += static_cast<long long>(mx_alt_weight(rs + tid / 3, rows, pad)) * v;
         }
         __syncthreads();                                                   // sred is zeroed again / reused below
+    }
+    if (over != 0) {                                                       // (uniform) the last group's sums start `over` pixels into its bytes
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const int v3 = o[j][k + 3], v6 = k + 6 < 12 ? o[j][k + 6] : 0, v9 = k + 9 < 12 ? o[j][k + 9] : 0;
+                o[j][k] = last[j] ? (over == 1 ? v3 : (over == 2 ? v6 : v9)) : o[j][k];
+            }
     }
 #pragma unroll
     for (int j = 0; j < G; ++j)
