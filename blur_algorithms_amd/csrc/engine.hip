@@ -1663,6 +1663,16 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     const uint8_t* lo = d_src < d_dst ? d_src : d_dst;
     const uint8_t* hi = d_src < d_dst ? d_dst : d_src;
     if (static_cast<size_t>(hi - lo) < px * 3 * nframes) {
+        // (a large batch: in parts of at most 1 GiB, the cap of every engine's workspace -- frames are disjoint, so a part's result
+        // never touches a later part's source)
+        const size_t cap = std::max<size_t>(1, (static_cast<size_t>(1) << 30) / (px * 3));
+        if (d_src == d_dst && static_cast<size_t>(nframes) > cap) {
+            for (int f0 = 0; f0 < nframes; f0 += static_cast<int>(cap)) {
+                const int nf = std::min<int>(static_cast<int>(cap), nframes - f0);
+                if (int rc = run_fx_u8c3(ctx, d_src + static_cast<size_t>(f0) * px * 3, d_dst + static_cast<size_t>(f0) * px * 3, nf, rows, cols, p, vdump)) return rc;
+            }
+            return BLUR_OK;
+        }
         if (int rc = ensure_work(ctx, px * 3 * nframes)) return rc;
         HIP_TRY(ctx, hipMemcpyAsync(ctx->work, d_src, px * 3 * nframes, hipMemcpyDeviceToDevice, ctx->stream));
         d_src = reinterpret_cast<const uint8_t*>(ctx->work);
@@ -1873,14 +1883,16 @@ int blur_gaussian_u8c3_host(blur_ctx* ctx, const uint8_t* src, uint8_t* dst, int
     if (!ctx) return BLUR_ERR_INVALID;
     if (!src || !dst || rows <= 0 || cols <= 0) return fail(ctx, BLUR_ERR_INVALID, "null image or non-positive size");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const size_t bytes = static_cast<size_t>(rows) * cols * 3;
+    const size_t bytes = static_cast<size_t>(rows) * cols * 3, half = (bytes + 255) & ~static_cast<size_t>(255);
     void* dv = nullptr;
-    if (int rc0 = ensure_host_stage(ctx, bytes, &dv)) return rc0;
+    // two device images, source and destination: the fused engine reads its neighbours' pixels while it writes and would otherwise
+    // copy an in-place frame into its workspace first
+    if (int rc0 = ensure_host_stage(ctx, 2 * half, &dv)) return rc0;
     uint8_t* d = static_cast<uint8_t*>(dv);
     int rc = BLUR_OK;
     hipError_t e = hipMemcpyAsync(d, src, bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) rc = blur_gaussian_u8c3_dev(ctx, d, d, rows, cols, sigma, opts);
-    if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpyAsync(dst, d, bytes, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) rc = blur_gaussian_u8c3_dev(ctx, d, d + half, rows, cols, sigma, opts);
+    if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpyAsync(dst, d + half, bytes, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->err = std::string("host blur: ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
     return rc;
@@ -1912,7 +1924,7 @@ int blur_gaussian_u8c3_host_batch(blur_ctx* ctx, const uint8_t* src, uint8_t* ds
             if (p.buf[k]) { HIP_TRY(ctx, hipFree(p.buf[k])); p.buf[k] = nullptr; }
         }
         p.bytes = 0;
-        for (int k = 0; k < S; ++k) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&p.buf[k]), fb));
+        for (int k = 0; k < S; ++k) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&p.buf[k]), 2 * ((fb + 255) & ~static_cast<size_t>(255))));   // input | output
         p.bytes = fb;
     }
     int rc = BLUR_OK;
@@ -1924,11 +1936,12 @@ int blur_gaussian_u8c3_host_batch(blur_ctx* ctx, const uint8_t* src, uint8_t* ds
         if (!step(hipMemcpyAsync(p.buf[k], src + static_cast<size_t>(i) * fb, fb, hipMemcpyHostToDevice, p.h2d))) break;
         if (!step(hipEventRecord(p.in_done[k], p.h2d))) break;
         if (!step(hipStreamWaitEvent(ctx->stream, p.in_done[k], 0))) break;
-        rc = blur_gaussian_u8c3_dev(ctx, p.buf[k], p.buf[k], rows, cols, sigma, opts);
+        uint8_t* const obuf = p.buf[k] + ((fb + 255) & ~static_cast<size_t>(255));           // out of place: no copy into the workspace
+        rc = blur_gaussian_u8c3_dev(ctx, p.buf[k], obuf, rows, cols, sigma, opts);
         if (rc != BLUR_OK) break;
         if (!step(hipEventRecord(p.comp_done[k], ctx->stream))) break;
         if (!step(hipStreamWaitEvent(p.d2h, p.comp_done[k], 0))) break;
-        if (!step(hipMemcpyAsync(dst + static_cast<size_t>(i) * fb, p.buf[k], fb, hipMemcpyDeviceToHost, p.d2h))) break;
+        if (!step(hipMemcpyAsync(dst + static_cast<size_t>(i) * fb, obuf, fb, hipMemcpyDeviceToHost, p.d2h))) break;
         if (!step(hipEventRecord(p.out_done[k], p.d2h))) break;
     }
     // drain everything that was queued, whatever happened above
@@ -1949,13 +1962,14 @@ int blur_gaussian_u8c3_host_pitched(blur_ctx* ctx, const uint8_t* src, size_t sr
         return fail(ctx, BLUR_ERR_INVALID, "null image, non-positive size or pitch shorter than a row");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     void* dv = nullptr;
-    if (int rc0 = ensure_host_stage(ctx, row_bytes * rows, &dv)) return rc0;
+    const size_t half = (row_bytes * rows + 255) & ~static_cast<size_t>(255);
+    if (int rc0 = ensure_host_stage(ctx, 2 * half, &dv)) return rc0;
     uint8_t* d = static_cast<uint8_t*>(dv);
     int rc = BLUR_OK;
-    // the rows are packed on the way in and unpacked on the way out (cv::Mat::step of a ROI or padded Mat)
+    // the rows are packed on the way in and unpacked on the way out (cv::Mat::step of a ROI or padded Mat); out of place on the device
     hipError_t e = hipMemcpy2DAsync(d, row_bytes, src, src_pitch, row_bytes, rows, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) rc = blur_gaussian_u8c3_dev(ctx, d, d, rows, cols, sigma, opts);
-    if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpy2DAsync(dst, dst_pitch, d, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) rc = blur_gaussian_u8c3_dev(ctx, d, d + half, rows, cols, sigma, opts);
+    if (e == hipSuccess && rc == BLUR_OK) e = hipMemcpy2DAsync(dst, dst_pitch, d + half, row_bytes, row_bytes, rows, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) { ctx->err = std::string("host blur (pitched): ") + hipGetErrorString(e); return BLUR_ERR_HIP; }
     return rc;

@@ -47,3 +47,47 @@ def test_multi_handle_on_the_c4_shard_shape(ctx):
         want = ctx.pffft_(t, 20.0, out=torch.empty_like(t)).cpu().numpy()
         assert np.array_equal(got[lo:lo + 8], want)
         del t
+
+
+def test_two_contexts_two_host_threads_fused_kernel_concurrently():
+    """two blur_ctx on device 0, each with its own stream, driven from two host threads at the same time (ctypes releases the GIL
+    during a call): the closest a one-GPU box gets to blur_multi_* on distinct devices.  Every context sets the kernels' LDS
+    attribute for its device itself (fx_attr_needed: per device, not per process) and the two launches share the chip; each thread's
+    bytes equal the single-context result, over several rounds and three kernel widths"""
+    import threading
+    import torch
+    import blur_algorithms_amd as B
+    ref = B.BlurContext(0)
+    work = []
+    for i, (rows, cols, sigma) in enumerate(((540, 964, 20.0), (360, 641, 12.0), (700, 1283, 30.0))):
+        img = torch.from_numpy(np.random.default_rng(100 + i).integers(0, 256, (2, rows, cols, 3), dtype=np.uint8)).cuda()
+        want = ref.pffft_(img, sigma, out=torch.empty_like(img), engine="fused").cpu().numpy()
+        work.append((img, sigma, want))
+    torch.cuda.synchronize()
+    errors = []
+
+    def run(tid):
+        try:
+            ctx = B.BlurContext(0)
+            st = torch.cuda.Stream(device=0)
+            ctx.set_stream(st.cuda_stream)
+            for rnd in range(6):
+                img, sigma, want = work[(rnd + tid) % len(work)]
+                out = torch.empty_like(img)
+                o = ctx._opts(True, 0, False, 0, False, None, "fused")
+                import ctypes as C
+                ctx._check(ctx._lib.blur_gaussian_u8c3_batch_dev(ctx._h, img.data_ptr(), out.data_ptr(), img.shape[0], img.shape[1], img.shape[2], float(sigma), C.byref(o)))
+                ctx.synchronize()
+                if not np.array_equal(out.cpu().numpy(), want):
+                    errors.append("thread %d round %d: bytes differ" % (tid, rnd))
+            ctx.close()
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (tid, e))
+
+    threads = [threading.Thread(target=run, args=(t,)) for t in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    ref.close()
+    assert not errors, errors
