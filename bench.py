@@ -106,9 +106,9 @@ def baseline_metric():
         return "megapixels/sec Gaussian blur (\u03c3=20, 4K RGB) at 1/2/4/8 GPUs; % HBM roofline"
 
 
-FAMILY_PREFIX = {0: "rowpass_kernel", 1: "fast_", 2: "wr_", 4: "mx_", 6: "fx_"}
+FAMILY_PREFIX = {0: "rowpass_kernel", 1: "fast_", 2: "wr_", 4: "mx_", 6: "fx_", 7: "wr_"}
 FAMILY_NAME = {0: "run-time-planned FFT kernels", 1: "specialised rows-first FFT kernels", 2: "wave-resident FFT kernels", 3: "whole-image 2D FFT",
-               4: "matrix-core kernels (two passes)", 6: "fused matrix-core kernel"}
+               4: "matrix-core kernels (two passes)", 6: "fused matrix-core kernel", 7: "tiled wave-resident FFT kernels"}
 DTYPE = {4: "f16 hi+lo operands (u8 pixels exact, taps split in two binary16 halves), f32 accumulate, 24-bit fixed-point intermediate",
          6: "f16 hi+lo operands (u8 pixels exact, taps and intermediate split in two binary16 halves), f32 accumulate"}
 

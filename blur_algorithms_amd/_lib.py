@@ -21,7 +21,7 @@ class BlurError(RuntimeError):
 
 class BlurOpts(C.Structure):
     _fields_ = [("nyquist_quirk", C.c_int), ("col_group", C.c_int), ("force_generic", C.c_int), ("frames_per_launch", C.c_int),
-                ("row_major_planes", C.c_int), ("engine", C.c_int), ("reserved", C.c_int * 2)]
+                ("row_major_planes", C.c_int), ("engine", C.c_int), ("tile_points", C.c_int), ("reserved", C.c_int * 1)]
 
 
 # every symbol include/blur_amd.h declares: name -> (restype, argtypes)

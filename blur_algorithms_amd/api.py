@@ -125,10 +125,10 @@ class BlurContext:
             raise BlurError(rc, self._lib.blur_last_error(self._h).decode())
 
     def _opts(self, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0, row_major_planes=False,
-              wave_resident=None, engine=None):
+              wave_resident=None, engine=None, tile_points=0):
         # one blur_opts per distinct argument tuple, built once (a call on a small image is tens of microseconds of GPU time: the
         # wrapper must not cost more than the kernels)
-        key = (bool(nyquist_quirk), int(col_group), bool(force_generic), int(frames_per_launch), bool(row_major_planes), wave_resident, engine)
+        key = (bool(nyquist_quirk), int(col_group), bool(force_generic), int(frames_per_launch), bool(row_major_planes), wave_resident, engine, int(tile_points))
         cache = self.__dict__.setdefault("_opts_cache", {})
         o = cache.get(key)
         if o is not None:
@@ -136,7 +136,7 @@ class BlurContext:
         o = cache[key] = self._build_opts(*key)
         return o
 
-    def _build_opts(self, nyquist_quirk, col_group, force_generic, frames_per_launch, row_major_planes, wave_resident, engine):
+    def _build_opts(self, nyquist_quirk, col_group, force_generic, frames_per_launch, row_major_planes, wave_resident, engine, tile_points=0):
         o = BlurOpts()
         self._lib.blur_opts_default(C.byref(o))
         o.nyquist_quirk = 1 if nyquist_quirk else 0
@@ -153,6 +153,7 @@ class BlurContext:
         # "wave-resident" / "rows-first" = one FFT family
         if engine is not None:
             o.engine = ENGINES[engine]
+        o.tile_points = int(tile_points)      # tests: force the tiled wave-resident path with transforms of at most this many points
         return o
 
     def use_torch_stream(self):
@@ -208,13 +209,13 @@ class BlurContext:
 
     # -- pffft_(image, sigma): Source.cpp:429-570 -----------------------------------------
     def pffft_(self, image, sigma, out=None, nyquist_quirk=True, col_group=0, force_generic=False, frames_per_launch=0,
-               row_major_planes=False, wave_resident=None, engine=None):
+               row_major_planes=False, wave_resident=None, engine=None, tile_points=0):
         """Gaussian blur of a BGR/RGB uint8 image [rows, cols, 3] or a batch [n, rows, cols, 3].
 
         torch CUDA tensor: asynchronous on torch's current stream, returns `out`
         (default: in place, like the reference).  numpy array: host round trip, returns a new array.
         """
-        o = self._opts(nyquist_quirk, col_group, force_generic, frames_per_launch, row_major_planes, wave_resident, engine)
+        o = self._opts(nyquist_quirk, col_group, force_generic, frames_per_launch, row_major_planes, wave_resident, engine, tile_points)
         if isinstance(image, np.ndarray):
             if (image.dtype == np.uint8 and image.ndim == 3 and image.shape[2] == 3 and not image.flags["C_CONTIGUOUS"]
                     and image.strides[2] == 1 and image.strides[1] == 3 and image.strides[0] >= 3 * image.shape[1]):

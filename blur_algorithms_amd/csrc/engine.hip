@@ -226,6 +226,74 @@ __global__ __launch_bounds__(256) void interleave_kernel(const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------
+// tiled wave-resident path (run_wr_tiled): the Nyquist-slot quirk's two term vectors from fx_prepass's integer sums
+//   e[f][c][x] = dc Ccol(x, c)                                                (x < pitch; 0 right of the image)
+//   h[f][c][r] = dr (colconv(Srow)(r, c) + dc (-1)^(r + pad) Z(c))            (the column convolution with reflect-101, in double)
+// grid (ne + nh blocks of 256 outputs, frames): the first ne = ceil(pitch / 256) blocks make e, the others h
+// dynamic LDS: 3 (256 + 2 pad) + 2 pad + 1 + 3 + 3 x 256 doubles
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tl_terms_kernel(const int* __restrict__ srow_part, const int* __restrict__ cpart, const long long* __restrict__ zpart,
+                                                       const float* __restrict__ taps, float* __restrict__ e, float* __restrict__ h, int rows, int cols, int pad,
+                                                       int pitch, int nbatches, int nbands, int cpitch, float dr, float dc, int ne)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char tl_lds[];
+    const int f = blockIdx.y, tid = threadIdx.x;
+    if (static_cast<int>(blockIdx.x) < ne) {
+        const int x = blockIdx.x * 256 + tid;
+        if (x >= pitch) return;
+        for (int c = 0; c < 3; ++c) {
+            long long sum = 0;
+            if (x < cols)
+                for (int b = 0; b < nbands; ++b) sum += cpart[(static_cast<size_t>(f) * nbands + b) * cpitch + 3 * x + c];
+            e[(static_cast<size_t>(f) * 3 + c) * pitch + x] = static_cast<float>(static_cast<double>(dc) * static_cast<double>(sum));
+        }
+        return;
+    }
+    const int r0 = (blockIdx.x - ne) * 256, win = 256 + 2 * pad, ntap = 2 * pad + 1;
+    double* sr = reinterpret_cast<double*>(tl_lds);            // [3][win]
+    double* tp = sr + 3 * win;
+    double* zs = tp + ntap;                                    // [3]
+    double* zr = zs + 3;                                       // [3][256] partial sums of Z
+    for (int i = tid; i < 3 * win; i += 256) {
+        const int c = i / win, p = i - c * win;
+        const int r = mx_refl(r0 - pad + p, rows);
+        long long v = 0;
+        for (int b = 0; b < nbatches; ++b) v += srow_part[((static_cast<size_t>(f) * nbatches + b) * rows + r) * 3 + c];
+        sr[i] = static_cast<double>(v);
+    }
+    for (int i = tid; i < ntap; i += 256) tp[i] = static_cast<double>(taps[i]);
+    {
+        const int nz = nbands * nbatches;
+        long long z[3] = { 0, 0, 0 };
+        for (int i = tid; i < nz; i += 256)
+            for (int c = 0; c < 3; ++c) z[c] += zpart[(static_cast<size_t>(f) * nz + i) * 3 + c];
+        for (int c = 0; c < 3; ++c) zr[c * 256 + tid] = static_cast<double>(z[c]);      // (exact: |Z| < 2^53)
+    }
+    __syncthreads();
+    if (tid < 3) {
+        double z = 0;
+        for (int i = 0; i < 256; ++i) z += zr[tid * 256 + i];
+        zs[tid] = z;
+    }
+    __syncthreads();
+    const int r = r0 + tid;
+    if (r >= rows) return;
+    const double sg = ((r + pad) & 1) ? -1.0 : 1.0;
+    for (int c = 0; c < 3; ++c) {
+        const double* s = sr + c * win + tid;
+        double acc[4] = { 0, 0, 0, 0 };
+        int t = 0;
+        for (; t + 4 <= ntap; t += 4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = __builtin_fma(tp[t + j], s[t + j], acc[j]);
+        }
+        for (; t < ntap; ++t) acc[0] = __builtin_fma(tp[t], s[t], acc[0]);
+        h[(static_cast<size_t>(f) * 3 + c) * rows + r] =
+            static_cast<float>(static_cast<double>(dr) * (((acc[0] + acc[1]) + (acc[2] + acc[3])) + static_cast<double>(dc) * sg * zs[c]));
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // fastboxblur: one sweep of the sliding accumulator along lines of length n.
 // Element (line l, position x, channel c) at buf[l*lstride + x*xstride + c].
 // A wave owns 64 adjacent (line, channel) accumulators; along the line it walks
@@ -667,6 +735,14 @@ struct blur_ctx {
     size_t fx_strips_bytes = 0;
     int* fx_sums = nullptr;         // fused kernel, quirk: the pre-pass's partial sums (run_fx_u8c3)
     size_t fx_sums_bytes = 0;
+    // tiled wave-resident path: the quirk's sums and term vectors of one frame, a copy of an in-place frame, the taps per kernel
+    int* tl_sums = nullptr;
+    size_t tl_sums_bytes = 0;
+    float* tl_terms = nullptr;
+    size_t tl_terms_bytes = 0;
+    uint8_t* tl_copy = nullptr;
+    size_t tl_copy_bytes = 0;
+    std::map<std::pair<uint64_t, int>, float*> tl_taps;      // (sigma bits, kSize) -> 2 pad + 1 taps on the device
     int* mx_sums = nullptr;
     size_t mx_sums_bytes = 0;
     float* mx_terms = nullptr;
@@ -968,6 +1044,18 @@ struct Prepared {
     const MxTables* mxt = nullptr;
     int mx_vpitch = 0;
     bool mx_quirk = false;
+    // tiled wave-resident path (run_wr_tiled): bands of rows for the column pass, tiles of columns for the row pass
+    struct Span { int in0, in1, padmode, v0, v1; };      // lines [in0, in1) go in (padmode = pad: reflect-101 at both ends; 0: none), [v0, v1) are kept
+    std::vector<Span> bands, tiles;
+    const WrEntry *tl_col = nullptr;                      // one column kernel for every band
+    std::vector<const WrEntry*> tl_row;                   // a row kernel per tile
+    std::vector<float*> tl_m_row;
+    std::vector<float2*> tl_tw0_row;
+    float* tl_m_col = nullptr;
+    float2* tl_tw0_col = nullptr;
+    float tl_dr = 0.f, tl_dc = 0.f;
+    float* tl_taps = nullptr;                             // device: the 2 pad + 1 taps
+    bool tiled = false, tl_quirk = false;
 };
 
 // a caller-supplied separable kernel instead of the Gaussian: taps (odd count, centre in the middle)
@@ -1147,6 +1235,150 @@ static FftFamilyChoice fft_family_choice(int rows, int cols, const Sizing& sz)
     return c;
 }
 
+// ---- tiled wave-resident path: spans along one axis --------------------------------------------------------------------------
+// Cuts `len` lines with a kernel of half width `pad` into spans a transform of at most `nmax` points and `in_max` input lines can take.
+// The first and the last span end at an image border and are padded by the kernel itself (reflect-101, padmode = pad: in + 2 pad
+// points); the spans between are circular convolutions of real pixels only (padmode = 0: in points) whose first `halo` (= pad rounded
+// up to `align`, so that the kept part starts at a multiple of `align`) and last pad results are not kept.  False: pad too wide.
+static bool plan_spans(int len, int pad, int nmax, int in_max, int align, std::vector<Prepared::Span>& out)
+{
+    out.clear();
+    if (in_max > nmax) in_max = nmax;
+    if (len + 2 * pad <= nmax && len <= in_max) { out.push_back({ 0, len, pad, 0, len }); return true; }
+    const int halo = (pad + align - 1) / align * align;
+    const int le = std::min(nmax - 2 * pad, in_max), lm = in_max;
+    int ve = (le - halo) / align * align, vm = (lm - halo - pad) / align * align;        // most kept lines of an edge / a middle span
+    if (ve <= 0 || vm <= 0) return false;
+    // boundaries: as few spans as possible, evened out (one or two more where the even split breaks a limit)
+    int nsp0 = 2;
+    if (len > 2 * ve) nsp0 += (len - 2 * ve + vm - 1) / vm;
+    std::vector<int> b;
+    int nsp = 0;
+    for (int tries = 0; tries < 4 && nsp == 0; ++tries) {
+        const int n = nsp0 + tries;
+        b.assign(n + 1, 0);
+        b[n] = len;
+        // edge spans take the same share as the middle ones where that fits their limit
+        int e = static_cast<int>(static_cast<long long>(len) / n) / align * align;
+        if (e > ve) e = ve;
+        if (e < align) e = align;
+        b[1] = e;
+        const int rest = len - 2 * e;
+        for (int i = 2; i < n; ++i) b[i] = (e + static_cast<int>(static_cast<long long>(rest) * (i - 1) / (n - 2))) / align * align;
+        b[n - 1] = std::max(b[n - 1], (len - ve + align - 1) / align * align);             // the last span's limit
+        bool ok = len - b[n - 1] <= ve && len - b[n - 1] > 0 && b[1] <= ve;
+        for (int i = 1; i < n && ok; ++i) ok = b[i] > b[i - 1];
+        for (int i = 1; i + 1 < n && ok; ++i) ok = b[i + 1] - b[i] <= vm;
+        if (ok) nsp = n;
+    }
+    if (nsp == 0) return false;
+    for (int i = 0; i < nsp; ++i) {
+        Prepared::Span sp;
+        sp.v0 = b[i];
+        sp.v1 = b[i + 1];
+        if (i == 0) { sp.in0 = 0; sp.in1 = std::min(len, sp.v1 + pad); sp.padmode = pad; }
+        else if (i == nsp - 1) { sp.in0 = sp.v0 - halo; sp.in1 = len; sp.padmode = pad; }
+        else { sp.in0 = sp.v0 - halo; sp.in1 = std::min(len, sp.v1 + pad); sp.padmode = 0; }
+        if (sp.in0 < 0 || sp.in1 - sp.in0 + 2 * sp.padmode > nmax || sp.in1 - sp.in0 > in_max || sp.padmode > sp.in1 - sp.in0 - 1) return false;
+        out.push_back(sp);
+    }
+    return true;
+}
+
+// m[0] - m[n / 2] of the n-periodic kernel array as host_math's kernel_multipliers computes the two: float(Re DFT) * (1.f / n)
+static float quirk_gain(const float* karr, int n)
+{
+    long double k0 = 0, kalt = 0;
+    for (int i = 0; i < n; ++i) { k0 += karr[i]; kalt += (i & 1) ? -static_cast<long double>(karr[i]) : static_cast<long double>(karr[i]); }
+    const float scaler = 1.f / n;
+    return static_cast<float>(k0) * scaler - static_cast<float>(kalt) * scaler;
+}
+
+// the tiled wave-resident path for this frame: the column kernel and its bands, the row kernels and their tiles, the tables
+// (multipliers WITHOUT the quirk: it enters as the terms of tl_terms_kernel).  tile_points > 0 (tests): no transform longer than that.
+static int plan_tiled(blur_ctx* ctx, int rows, int cols, double sigma, bool quirk, int tile_points, Prepared& p)
+{
+    const int pad = p.sz.pad;
+    // one column kernel for all bands: the candidate that transforms the fewest points per column
+    long long best = -1;
+    for (int r0 : { 10, 9, 8, 6, 5, 4, 3 }) {
+        const int n = r0 * kWrS;
+        if (tile_points > 0 && n > tile_points) continue;
+        const WrEntry* e = find_wr_entry(n, true);
+        if (!e || e->r0 != r0) continue;
+        int in_max = n;
+        while (in_max > 0 && e->col_lds(in_max) > kLdsLimit) in_max -= 8;
+        std::vector<Prepared::Span> sp;
+        if (in_max <= 0 || !plan_spans(rows, pad, n, in_max, 1, sp)) continue;
+        const long long cost = static_cast<long long>(sp.size()) * n;
+        if (best < 0 || cost < best) { best = cost; p.bands = sp; p.tl_col = e; }
+    }
+    if (best < 0) return BLUR_ERR_UNSUPPORTED;
+    best = -1;
+    for (int r0 : { 16, 15, 12, 10, 9, 8, 6, 5, 4, 3 }) {
+        const int n = r0 * kWrS;
+        if (tile_points > 0 && n > tile_points) continue;
+        const WrEntry* e = find_wr_entry(n, false);
+        if (!e || e->r0 != r0) continue;
+        int in_max = n;
+        while (in_max > 0 && e->row_lds(in_max) > kLdsLimit) in_max -= 16;
+        std::vector<Prepared::Span> sp;
+        if (in_max <= 0 || !plan_spans(cols, pad, n, in_max, 16, sp)) continue;
+        const long long cost = static_cast<long long>(sp.size()) * n;
+        if (best < 0 || cost < best) { best = cost; p.tiles = sp; }
+    }
+    if (best < 0) return BLUR_ERR_UNSUPPORTED;
+    uint64_t bits;
+    std::memcpy(&bits, &sigma, sizeof bits);
+    auto spectrum = [&](int n, float** out) -> int {
+        const auto key = std::make_tuple(n, 0, p.sz.kSize, 0, bits);            // n_ref 0: no quirk in the table
+        std::vector<float> karr(n, 0.f);
+        if (ctx->wr_spectra.find(key) == ctx->wr_spectra.end()) {
+            std::vector<float> k(std::max(n, p.sz.kSize));
+            get_gaussian(k.data(), sigma, p.sz.kSize, n);                       // Source.cpp:75-102: taps rotated to index 0
+            std::copy(k.begin(), k.begin() + n, karr.begin());
+        }
+        return wr_get_spectrum(ctx, key, karr, n, n, false, out);
+    };
+    if (int rc = wr_get_tables(ctx, p.tl_col, &p.tl_tw0_col)) return rc;
+    if (int rc = spectrum(p.tl_col->r0 * kWrS, &p.tl_m_col)) return rc;
+    p.tl_row.clear(); p.tl_m_row.clear(); p.tl_tw0_row.clear();
+    for (const Prepared::Span& t : p.tiles) {
+        const WrEntry* e = find_wr_entry(t.in1 - t.in0 + 2 * t.padmode, false);
+        while (e && e->row_lds(t.in1 - t.in0) > kLdsLimit) e = find_wr_entry(e->r0 * kWrS + 1, false);
+        if (!e || (tile_points > 0 && e->r0 * kWrS > tile_points)) return BLUR_ERR_UNSUPPORTED;
+        float2* tw0 = nullptr;
+        float* m = nullptr;
+        if (int rc = wr_get_tables(ctx, e, &tw0)) return rc;
+        if (int rc = spectrum(e->r0 * kWrS, &m)) return rc;
+        p.tl_row.push_back(e); p.tl_tw0_row.push_back(tw0); p.tl_m_row.push_back(m);
+    }
+    // the quirk's gains at the REFERENCE's transform lengths (Source.cpp:420-425), and the taps
+    {
+        std::vector<float> k(std::max(std::max(p.sz.n_row, p.sz.n_col), p.sz.kSize));
+        get_gaussian(k.data(), sigma, p.sz.kSize, p.sz.n_row);
+        p.tl_dr = quirk_gain(k.data(), p.sz.n_row);
+        std::vector<float> taps(2 * pad + 1);
+        for (int t = -pad; t <= pad; ++t) taps[t + pad] = k[(t + p.sz.n_row) % p.sz.n_row];
+        get_gaussian(k.data(), sigma, p.sz.kSize, p.sz.n_col);
+        p.tl_dc = quirk_gain(k.data(), p.sz.n_col);
+        const auto tk = std::make_pair(bits, p.sz.kSize);
+        auto it = ctx->tl_taps.find(tk);
+        if (it == ctx->tl_taps.end()) {
+            float* d = nullptr;
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&d), taps.size() * sizeof(float)));
+            HIP_TRY(ctx, hipMemcpy(d, taps.data(), taps.size() * sizeof(float), hipMemcpyHostToDevice));
+            it = ctx->tl_taps.emplace(tk, d).first;
+        }
+        p.tl_taps = it->second;
+    }
+    p.frame_elems = 0;
+    for (const Prepared::Span& b : p.bands) p.frame_elems = std::max(p.frame_elems, wr_frame_floats(b.in1 - b.in0, cols, b.padmode));
+    p.tiled = true;
+    p.tl_quirk = quirk;
+    return BLUR_OK;
+}
+
 static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_opts* opts, Prepared& p, bool u8c3 = true,
                    const CustomKernel* ck = nullptr, bool allow_wr = true, bool ptrs_aligned = false)
 {
@@ -1248,6 +1480,24 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         p.mx_quirk = quirk;
         p.frame_elems = static_cast<size_t>(mx_vrows(rows, me->nkb)) * vpitch;
         return BLUR_OK;
+        }
+    }
+    // Tiled wave-resident path (round 4): lines longer than the longest wave-resident transform -- sigma = sqrt(side) on large images,
+    // the reference's own benchmark (Source.cpp:627-635) -- in bands and tiles through the same kernels, instead of the run-time-planned
+    // kernels (three to four times slower).  Taken where neither the whole-image wave-resident pair nor the rows-first family's
+    // compile-time kernels apply; blur_opts.tile_points > 0 forces it (tests).
+    {
+        const int tile_points = opts ? opts->tile_points : 0;
+        if (allow_fast && allow_wr && u8c3 && !ck && !(opts && opts->engine == BLUR_ENGINE_FFT_ROWS_FIRST)) {
+            const FftFamilyChoice fc0 = fft_family_choice(rows, cols, p.sz);
+            const bool whole = fc0.fits && ((opts && opts->engine == BLUR_ENGINE_FFT_WAVE_RESIDENT) || fc0.wr_pays);
+            if (tile_points > 0 || (!whole && !fc0.old_both)) {
+                const int rc = plan_tiled(ctx, rows, cols, sigma, quirk, tile_points, p);
+                if (rc == BLUR_OK) return BLUR_OK;
+                if (rc != BLUR_ERR_UNSUPPORTED) return rc;
+                if (tile_points > 0) return fail(ctx, BLUR_ERR_UNSUPPORTED, "tiled wave-resident path: the kernel is too wide for transforms of tile_points points");
+                p.bands.clear(); p.tiles.clear();
+            }
         }
     }
     // Wave-resident kernels first (reserved[3] = 1 switches them off): both passes need one, and its LDS must hold the image
@@ -1532,6 +1782,10 @@ int blur_ctx_destroy(blur_ctx* ctx)
     for (auto& lt : ctx->lines_tables) (void)hipFree(lt.dev);
     if (ctx->fx_strips) (void)hipFree(ctx->fx_strips);
     if (ctx->fx_sums) (void)hipFree(ctx->fx_sums);
+    if (ctx->tl_sums) (void)hipFree(ctx->tl_sums);
+    if (ctx->tl_terms) (void)hipFree(ctx->tl_terms);
+    if (ctx->tl_copy) (void)hipFree(ctx->tl_copy);
+    for (auto& kv : ctx->tl_taps) (void)hipFree(kv.second);
     if (ctx->mx_sums) (void)hipFree(ctx->mx_sums);
     if (ctx->mx_terms) (void)hipFree(ctx->mx_terms);
     if (ctx->work) (void)hipFree(reinterpret_cast<char*>(ctx->work) - kWorkGuard);
@@ -1753,6 +2007,112 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
     return BLUR_OK;
 }
 
+static bool bands_overlap(const uint8_t* lo, const uint8_t* hi, size_t bytes) { return static_cast<size_t>(hi - lo) < bytes; }
+
+// Tiled wave-resident path (prepare(): plan_tiled): frame by frame, the quirk's sums (fx_prepass) and terms (tl_terms_kernel), then
+// per band of rows the column kernel and per tile of columns the row kernel.  Intermediate: one band at a time in the workspace.
+static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes, int rows, int cols, const Prepared& p)
+{
+    const size_t px = static_cast<size_t>(rows) * cols, fb = px * 3;
+    const int pad = p.sz.pad;
+    if (int rc = ensure_work(ctx, p.frame_elems * sizeof(float))) return rc;
+    float* const inter = reinterpret_cast<float*>(ctx->work);
+    const int groups = (cols + 3) / 4, gpt = fx_groups_per_thread(cols);
+    if (p.tl_quirk && (gpt == 0 || cols < 4)) return fail(ctx, BLUR_ERR_UNSUPPORTED, "tiled wave-resident path: image width outside 4 .. 16384 (the quirk's pre-pass)");
+    const int pitch = (cols + 7) & ~7;
+    int *srow = nullptr, *cpart = nullptr;
+    long long* zpart = nullptr;
+    float *e = nullptr, *h = nullptr;
+    int band_rows = 0, nbands = 0, nbatches = 0;
+    if (p.tl_quirk) {
+        band_rows = fx_band_rows(rows, cols, 1, ctx->num_cus);
+        nbands = (rows + band_rows - 1) / band_rows;
+        nbatches = (groups + 256 * gpt - 1) / (256 * gpt);
+        auto up4 = [](size_t v) { return (v + 3) & ~static_cast<size_t>(3); };
+        const size_t n_srow = up4(static_cast<size_t>(nbatches) * rows * 3), n_cpart = up4(static_cast<size_t>(nbands) * 12 * groups);
+        const size_t n_z = static_cast<size_t>(nbands) * nbatches * 3;
+        const size_t bytes = (n_srow + n_cpart) * sizeof(int) + n_z * sizeof(long long) + 64;
+        if (ctx->tl_sums_bytes < bytes) {
+            if (ctx->tl_sums) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->tl_sums)); ctx->tl_sums = nullptr; ctx->tl_sums_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->tl_sums), bytes));
+            ctx->tl_sums_bytes = bytes;
+        }
+        srow = ctx->tl_sums;
+        cpart = srow + n_srow;
+        zpart = reinterpret_cast<long long*>(cpart + n_cpart);
+        const size_t tbytes = (static_cast<size_t>(3) * pitch + static_cast<size_t>(3) * rows) * sizeof(float) + 64;
+        if (ctx->tl_terms_bytes < tbytes) {
+            if (ctx->tl_terms) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->tl_terms)); ctx->tl_terms = nullptr; ctx->tl_terms_bytes = 0; }
+            HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->tl_terms), tbytes));
+            ctx->tl_terms_bytes = tbytes;
+        }
+        e = ctx->tl_terms;
+        h = e + static_cast<size_t>(3) * pitch;
+    }
+    for (int f = 0; f < nframes; ++f) {
+        const uint8_t* src = d_src + static_cast<size_t>(f) * fb;
+        uint8_t* dst = d_dst + static_cast<size_t>(f) * fb;
+        // in place (or overlapping): a band reads rows the band before it has already written
+        const uint8_t* lo = src < dst ? src : dst;
+        const uint8_t* hi = src < dst ? dst : src;
+        if (bands_overlap(lo, hi, fb) && (p.bands.size() > 1 || p.tiles.size() > 1 || src == dst)) {
+            if (ctx->tl_copy_bytes < fb) {
+                if (ctx->tl_copy) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(ctx->tl_copy)); ctx->tl_copy = nullptr; ctx->tl_copy_bytes = 0; }
+                HIP_TRY(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->tl_copy), fb));
+                ctx->tl_copy_bytes = fb;
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->tl_copy, src, fb, hipMemcpyDeviceToDevice, ctx->stream));
+            src = ctx->tl_copy;
+        }
+        if (p.tl_quirk) {
+            TimedLaunch t(ctx, 1, 1);
+            const int n_alt = nbands * nbatches;
+            auto kern = gpt == 1 ? fx_prepass<1> : (gpt == 2 ? fx_prepass<2> : fx_prepass<4>);
+            hipLaunchKernelGGL(kern, dim3(n_alt), dim3(256), 0, ctx->stream, src, srow, cpart, zpart, nullptr, rows, cols, pad, 0, nbands, nbatches, n_alt, 1, 0, 1, band_rows);
+            HIP_TRY(ctx, hipGetLastError());
+            const int ne = (pitch + 255) / 256, nh = (rows + 255) / 256;
+            const size_t lds = (static_cast<size_t>(3) * (256 + 2 * pad) + (2 * pad + 1) + 3 + 3 * 256) * sizeof(double);
+            if (lds > 64 * 1024) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(tl_terms_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            hipLaunchKernelGGL(tl_terms_kernel, dim3(ne + nh, 1), dim3(256), lds, ctx->stream, srow, cpart, zpart, p.tl_taps, e, h, rows, cols, pad, pitch, nbatches, nbands,
+                               12 * groups, p.tl_dr, p.tl_dc, ne);
+            HIP_TRY(ctx, hipGetLastError());
+        }
+        for (const Prepared::Span& b : p.bands) {
+            const int brows = b.in1 - b.in0;
+            WrColTerm term;
+            if (p.tl_quirk) {
+                term.e = e;
+                term.pitch = pitch;
+                term.sign = ((b.in0 + pad - b.padmode) & 1) ? -1.f : 1.f;       // (-1)^(image row + pad) of slot 0: slot = (band row + padmode) & 1
+            }
+            { TimedLaunch t(ctx, 1, 1);
+              HIP_TRY(ctx, p.tl_col->col_u8(ctx->stream, src + static_cast<size_t>(b.in0) * cols * 3, inter, brows, cols, b.padmode, 1, ctx->num_cus, ctx->d_w256, p.tl_tw0_col,
+                                            p.tl_m_col, term)); }
+            const int npairs = wr_npairs(brows, b.padmode), strips_full = (cols + 7) / 8;
+            for (size_t ti = 0; ti < p.tiles.size(); ++ti) {
+                const Prepared::Span& t = p.tiles[ti];
+                WrRowTile tile;
+                tile.h = p.tl_quirk ? h : nullptr;
+                tile.rows_full = rows;
+                tile.row_base = b.in0;
+                tile.vr0 = b.v0;
+                tile.vr1 = b.v1;
+                tile.ypar = b.padmode & 1;
+                tile.dst_pitch = cols * 3;
+                tile.dst_x0 = t.in0;
+                tile.vc0 = t.v0 - t.in0;
+                tile.vc1 = t.v1 - t.in0;
+                tile.xpar = (t.in0 + pad) & 1;                                   // (-1)^(image column + pad): the call's column 0 is image column in0
+                tile.plane_strips = strips_full;
+                TimedLaunch tl(ctx, 0, 1);
+                HIP_TRY(ctx, p.tl_row[ti]->row_u8(ctx->stream, inter + static_cast<size_t>(t.in0 / 8) * npairs * 16, dst, brows, t.in1 - t.in0, t.padmode, 1, ctx->num_cus,
+                                                  ctx->d_w256, p.tl_tw0_row[ti], p.tl_m_row[ti], tile));
+            }
+        }
+    }
+    return BLUR_OK;
+}
+
 static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int nframes,
                                 int rows, int cols, double sigma, const blur_opts* opts, const CustomKernel* ck)
 {
@@ -1771,6 +2131,11 @@ static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_
         ctx->last_family = 6;
         return run_fx_u8c3(ctx, d_src, d_dst, nframes, rows, cols, p);
     }
+    if (p.tiled) {
+        if (nframes == 0) return BLUR_OK;
+        ctx->last_family = 7;
+        return run_wr_tiled(ctx, d_src, d_dst, nframes, rows, cols, p);
+    }
     int chunk = opts && opts->frames_per_launch > 0 ? opts->frames_per_launch : static_cast<int>((1024u << 20) / (p.frame_elems * sizeof(float)));
     if (chunk < 1) chunk = 1;
     if (chunk > nframes) chunk = nframes;
@@ -1785,9 +2150,9 @@ static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_
         if (p.wr_col) {
             // columns first, then rows (wr_kernels.hpp); timing slot 1 = column kernel, 0 = row kernel as elsewhere
             { TimedLaunch t(ctx, 1, nf);
-              HIP_TRY(ctx, p.wr_col->col_u8(ctx->stream, s, ctx->work, rows, cols, p.sz.pad, nf, ctx->num_cus, ctx->d_w256, p.wr_tw0_col, p.wr_m_col)); }
+              HIP_TRY(ctx, p.wr_col->col_u8(ctx->stream, s, ctx->work, rows, cols, p.sz.pad, nf, ctx->num_cus, ctx->d_w256, p.wr_tw0_col, p.wr_m_col, WrColTerm{})); }
             { TimedLaunch t(ctx, 0, nf);
-              HIP_TRY(ctx, p.wr_row->row_u8(ctx->stream, ctx->work, d, rows, cols, p.sz.pad, nf, ctx->num_cus, ctx->d_w256, p.wr_tw0_row, p.wr_m_row)); }
+              HIP_TRY(ctx, p.wr_row->row_u8(ctx->stream, ctx->work, d, rows, cols, p.sz.pad, nf, ctx->num_cus, ctx->d_w256, p.wr_tw0_row, p.wr_m_row, WrRowTile{})); }
             continue;
         }
         if (int rc = run_rowpass_u8c3(ctx, s, ctx->work, rows, cols, nf, p, p.tile_w)) return rc;
@@ -2461,9 +2826,9 @@ int blur_last_engine(const blur_ctx* ctx, char* note, size_t n)
 {
     if (!ctx) return -1;
     static const char* const names[] = { "run-time-planned FFT kernels", "specialised rows-first FFT kernels", "wave-resident FFT kernels", "whole-image 2D FFT",
-                                         "two-kernel matrix-core engine", "?", "fused matrix-core kernel" };
+                                         "two-kernel matrix-core engine", "?", "fused matrix-core kernel", "tiled wave-resident FFT kernels" };
     if (note && n > 0) {
-        std::string t = ctx->last_family >= 0 && ctx->last_family <= 6 ? names[ctx->last_family] : "none yet";
+        std::string t = ctx->last_family >= 0 && ctx->last_family <= 7 ? names[ctx->last_family] : "none yet";
         if (!ctx->engine_note.empty()) t += " (not taken: " + ctx->engine_note + ")";
         std::snprintf(note, n, "%s", t.c_str());
     }

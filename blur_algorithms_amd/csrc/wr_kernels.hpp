@@ -326,12 +326,40 @@ template <int R0, int C> __host__ __device__ constexpr size_t wr_col_lds(int row
     return static_cast<size_t>(C) * wr_col_line_stride<R0>() * sizeof(float2) + wr_tw0_bytes<R0>() + ((static_cast<size_t>(rows) + 1) * wr_col_stage_row<C>() + 15) / 16 * 16;
 }
 
+// Tiled images (engine.hip: run_wr_tiled): an image whose lines are longer than the longest wave-resident transform is cut into
+// bands of rows (column pass) and tiles of columns (row pass) with the kernel's reach of real pixels either side -- a band or tile
+// in the middle of the image is a circular convolution without any border (pad = 0 for the kernel; the contaminated ends are not
+// kept) -- and the Nyquist-slot quirk of pffft_() (Source.cpp:420-425), which is a property of the WHOLE padded line, enters as
+// rank-one terms made from the integer sums of fx_prepass:
+//   intermediate W'[r][x] = colconv(img)[r][x] + (-1)^(r + pad) e(x),   e(x) = dc Ccol(x)              (WrColTerm)
+//   out[r][x] = rowconv(W')[r][x] + (-1)^(x + pad) h(r),                h(r) = dr (colconv(Srow)(r) + dc (-1)^(r + pad) Z)   (WrRowTile)
+// with multiplier tables WITHOUT the quirk (blur_opts.nyquist_quirk = 0 is the same without the terms).
+struct WrColTerm {
+    const float* e = nullptr;      // [frame][channel][pitch]: e(x) per column (nullptr: no term)
+    int pitch = 0;                 // floats per (frame, channel): the image width rounded up to 8
+    float sign = 1.f;              // (-1)^(r + pad) of slot 0 of a row pair of this call
+};
+// what a row-pass call on a band / tile needs beyond the plain call (defaults = the whole image)
+struct WrRowTile {
+    const float* h = nullptr;      // [frame][channel][rows_full]: h(r) per image row (nullptr: no term)
+    int rows_full = 0;             // image rows (pitch of h, rows of the output frame); 0: the call's rows
+    int row_base = 0;              // image row of the call's row 0
+    int vr0 = 0, vr1 = 0;          // image rows [vr0, vr1) are written (vr1 = 0: every row of the call)
+    int ypar = -1;                 // parity of the row pairs ((row + pad of the COLUMN call) & 1 = slot); -1: pad & 1 of this call
+    int dst_pitch = 0;             // bytes between output rows (0: the call's cols * 3)
+    int dst_x0 = 0;                // image column of the call's column 0
+    int vc0 = 0, vc1 = 0;          // columns [vc0, vc1) of the call are written (vc1 = 0: all); vc0 a multiple of 16
+    int xpar = 0;                  // parity of (image column of the call's column 0 + the kernel's half width): sign of h's term
+    int plane_strips = 0;          // strips of 8 columns per channel plane of the intermediate (0: the call's)
+};
+
 // ELO / EHI: the first ELO and the last EHI rounds k of pass 0 may touch the reflected borders or the zero tail (index
 // arithmetic per element); the rounds between are interior for every thread (checked by the launcher).
 template <int R0, int C, int T, int ELO, int EHI>
 __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ src, float* __restrict__ inter,
                                                    int rows, int cols, int pad, int npairs, int nstrips, int nunits, int aligned8,
-                                                   const float2* __restrict__ w256, const float2* __restrict__ tw0g, const float* __restrict__ mult)
+                                                   const float2* __restrict__ w256, const float2* __restrict__ tw0g, const float* __restrict__ mult,
+                                                   WrColTerm term)
 {
     constexpr int CH = 3, G = 2 * C, RB = G * CH;
     constexpr int RS = wr_col_stage_row<C>();        // bytes between rows of the LDS byte stage
@@ -451,6 +479,19 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
     WR_STAMP(7);      // prologue: tables, first strip
     const size_t plane = static_cast<size_t>(nstrips) * npairs * (2 * G);     // floats per channel
 
+    // the term of the task whose inverse pass 0 is due: this lane's column of (strip, channel), slot 0 gets + , slot 1 -
+    float tv[IT0];
+#pragma unroll
+    for (int it = 0; it < IT0; ++it) tv[it] = 0.f;
+    auto load_term = [&](int ff, int strip_, int ch_) {
+        if (term.e == nullptr) return;                   // uniform
+#pragma unroll
+        for (int it = 0; it < IT0; ++it) {
+            const int g = tid + T * it;
+            const int x = strip_ * G + 2 * line_of(g) + (bfly_of(g) & 1);
+            tv[it] = term.sign * term.e[(static_cast<size_t>(ff) * CH + ch_) * term.pitch + (x < term.pitch ? x : 0)];
+        }
+    };
     // inverse pass 0 of the task whose output block is `out_blk`: LDS -> butterfly -> lane-pair exchange -> global
     auto inverse_pass0 = [&](float* out_blk) {
 #pragma unroll
@@ -466,7 +507,9 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
                 for (int k = 0; k < R0; ++k) {
                     // even lane: row p (slot 0) of columns 2l, 2l+1; odd lane: row p + 1 (slot 1) of the same columns
                     const float px = wr_dpp<0xB1>(v[k].x), py = wr_dpp<0xB1>(v[k].y);
-                    const float2 o = odd ? make_float2(py, v[k].y) : make_float2(v[k].x, px);
+                    float2 o = odd ? make_float2(py, v[k].y) : make_float2(v[k].x, px);
+                    o.x += tv[it];                        // (tiled images: the column pass's Nyquist-slot term e(x) (-1)^(r + pad), WrColTerm)
+                    o.y -= tv[it];
                     bool ok = true;
                     if (k < ELO || k >= R0 - EHI) {
                         const int t = ((j + k * kWrS) >> 1) - (pad >> 1);
@@ -536,6 +579,7 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
             __syncthreads();
             WR_STAMP(3);      // barrier after phase B (+ claim)
             prev_blk = inter + (static_cast<size_t>(f) * CH + ch) * plane + static_cast<size_t>(strip) * npairs * (2 * G);
+            load_term(f, strip, ch);
         }
     }
     if (prev_blk) inverse_pass0(prev_blk);
@@ -560,7 +604,8 @@ template <int R0> __host__ __device__ constexpr size_t wr_row_lds(int cols)
 template <int R0, int T, int ELO, int EHI>
 __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ inter, uint8_t* __restrict__ dst,
                                                    int rows, int cols, int pad, int npairs, int nstrips, int nunits, int aligned16,
-                                                   const float2* __restrict__ w256, const float2* __restrict__ tw0g, const float* __restrict__ mult)
+                                                   const float2* __restrict__ w256, const float2* __restrict__ tw0g, const float* __restrict__ mult,
+                                                   WrRowTile tile)
 {
     constexpr int CH = 3, C = 3, G = 8;
     constexpr int NSB = C * R0;
@@ -588,7 +633,7 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
 
     const int c = __builtin_amdgcn_readfirstlane(tid >> 8);     // the channel is the same for a whole wave: scalar
     const int j = tid & 255;
-    const size_t plane = static_cast<size_t>(nstrips) * npairs * (2 * G);
+    const size_t plane = static_cast<size_t>(tile.plane_strips > 0 ? tile.plane_strips : nstrips) * npairs * (2 * G);
     const int strip_step = npairs * (2 * G);                     // floats between the same pair of neighbouring strips
     // per-thread constants (loop invariant, a handful of registers): byte offset of column j - pad inside a (channel, pair)
     // record set -- interior rounds add k * 32 strips -- and of the reflected columns of the edge rounds (~0u: zero)
@@ -632,10 +677,22 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
 #pragma unroll
         for (int k = 0; k < R0; ++k) asm volatile("" ::"v"(pf[k].x), "v"(pf[k].y));
     };
+    // tiled images: the row pass's Nyquist-slot term (-1)^(x + pad) h(r) of the unit's two rows rides in the rounding constant
+    const int ypar = tile.ypar < 0 ? (pad & 1) : tile.ypar;
+    const int rows_out = tile.rows_full > 0 ? tile.rows_full : rows;
+    const float sxf = ((jm + tile.xpar) & 1) ? -1.f : 1.f;       // (256 k is even: one sign per thread)
+    auto half_of = [&](int uu, int slot) -> float {
+        if (tile.h == nullptr) return 0.5f;                      // uniform
+        const int ff = uu / npairs, tt = uu - ff * npairs;
+        int r = tile.row_base + 2 * tt - ypar + slot;
+        r = r < 0 ? 0 : (r >= rows_out ? rows_out - 1 : r);
+        return 0.5f + sxf * tile.h[(static_cast<size_t>(ff) * CH + c) * rows_out + r];
+    };
     // inverse pass 0 of the unit in `lines` -> "+0.5f, truncate" -> byte stage
-    auto inverse_pass0 = [&]() {
+    auto inverse_pass0 = [&](int uu) {
         float2 v[R0];
         const int j_ = wr_opaque(j);
+        const float ha = half_of(uu, 0), hb = half_of(uu, 1);
         wr_ip0_load<R0>(v, lines + c * (R0 * kWrSB), tw0, j_);
         uint8_t* const st_a_ = stage + wr_opaque(st_off);
 #pragma unroll
@@ -644,13 +701,35 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
             if (k < ELO || k >= R0 - EHI) { const int x = jm + k * kWrS; ok = x >= 0 && x < cols; }
             if (ok) {
                 uint8_t* s = st_a_ + k * (kWrS * CH);
-                s[0] = static_cast<uint8_t>(static_cast<int>(v[k].x + 0.5f));
-                s[stage_row] = static_cast<uint8_t>(static_cast<int>(v[k].y + 0.5f));
+                s[0] = static_cast<uint8_t>(static_cast<int>(v[k].x + ha));
+                s[stage_row] = static_cast<uint8_t>(static_cast<int>(v[k].y + hb));
             }
         }
     };
     // the two image rows of unit (f, t) out of the stage
     auto write_out = [&](int f, int t) {
+        if (tile.vr1 > 0 || tile.vc1 > 0 || tile.dst_pitch > 0) {
+            // a band / tile of a larger image: image rows [vr0, vr1) and the call's columns [vc0, vc1) only, rows dst_pitch apart;
+            // 16-byte pieces from the (aligned) stage to wherever they belong, then the odd bytes
+            const int vr1 = tile.vr1 > 0 ? tile.vr1 : tile.row_base + rows, vc1 = tile.vc1 > 0 ? tile.vc1 : cols;
+            const size_t pitch = tile.dst_pitch > 0 ? static_cast<size_t>(tile.dst_pitch) : static_cast<size_t>(rowbytes);
+            const int g0 = tile.row_base + 2 * t - ypar;         // image row of slot 0
+            const int nb = (vc1 - tile.vc0) * CH, n16 = nb >> 4;
+            for (int rb = 0; rb < 2; ++rb) {
+                const int gr = g0 + rb;
+                if (gr < tile.vr0 || gr >= vr1) continue;       // uniform
+                uint8_t* const o = dst + (static_cast<size_t>(f) * rows_out + gr) * pitch + static_cast<size_t>(tile.dst_x0 + tile.vc0) * CH;
+                const uint8_t* const sp = stage + rb * stage_row + tile.vc0 * CH;
+                typedef unsigned int wr_u32x4 __attribute__((ext_vector_type(4), aligned(1)));
+                for (int i = tid; i < n16; i += T) {
+                    const uint4 q = *reinterpret_cast<const uint4*>(sp + 16 * i);
+                    const wr_u32x4 w = { q.x, q.y, q.z, q.w };
+                    *reinterpret_cast<wr_u32x4*>(o + 16 * i) = w;
+                }
+                for (int i = 16 * n16 + tid; i < nb; i += T) o[i] = sp[i];
+            }
+            return;
+        }
         const int r0 = 2 * t - (pad & 1);                        // slot 0 row (may be -1), slot 1 row r0 + 1 (may be rows)
         uint8_t* const out0 = dst + (static_cast<size_t>(f) * rows + (r0 < 0 ? 0 : r0)) * rowbytes;
         const bool ok0 = r0 >= 0, ok1 = r0 + 1 < rows;
@@ -685,7 +764,7 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
     int pu = -1;      // previous unit (its inverse pass 0 and write-out are still due)
     for (int u = walk.begin; u < walk.end; u += walk.step) {
         // ---- phase A: inverse pass 0 of the previous unit, pass 0 of this one (in place, same elements per thread)
-        if (pu >= 0) inverse_pass0();
+        if (pu >= 0) inverse_pass0(pu);
         __builtin_amdgcn_sched_barrier(0);      // one half after the other: together they do not fit the register budget
         WR_STAMP(4);      // inverse pass 0
         {
@@ -723,7 +802,7 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
         pu = u;
     }
     if (pu >= 0) {
-        inverse_pass0();
+        inverse_pass0(pu);
         __syncthreads();
         write_out(pu / npairs, pu % npairs);
     }
@@ -789,11 +868,11 @@ struct WrEntry {
     int threads;
     // columns first: u8 frames -> intermediate
     hipError_t (*col_u8)(hipStream_t, const uint8_t* src, float* inter, int rows, int cols, int pad, int nframes, int num_cus,
-                         const float2* w256, const float2* tw0, const float* mult);
+                         const float2* w256, const float2* tw0, const float* mult, WrColTerm term);
     size_t (*col_lds)(int rows);
     // rows second: intermediate -> u8 frames
     hipError_t (*row_u8)(hipStream_t, const float* inter, uint8_t* dst, int rows, int cols, int pad, int nframes, int num_cus,
-                         const float2* w256, const float2* tw0, const float* mult);
+                         const float2* w256, const float2* tw0, const float* mult, WrRowTile tile);
     size_t (*row_lds)(int cols);
     // complex lines of length N (in == out allowed)
     hipError_t (*lines)(hipStream_t, const float2* in, float2* out, int nlines, int num_cus, const float2* w256, const float2* tw0, const float* mult);
@@ -817,7 +896,7 @@ template <class K> hipError_t wr_set_lds(K kern, size_t lds)
 
 template <int R0, int C, int T>
 hipError_t wr_launch_col_u8(hipStream_t st, const uint8_t* src, float* inter, int rows, int cols, int pad, int nframes, int num_cus,
-                            const float2* w256, const float2* tw0, const float* mult)
+                            const float2* w256, const float2* tw0, const float* mult, WrColTerm term)
 {
     if (rows + 2 * pad > R0 * kWrS || pad > rows - 1) return hipErrorInvalidValue;
     const size_t lds = wr_col_lds<R0, C>(rows);
@@ -830,24 +909,25 @@ hipError_t wr_launch_col_u8(hipStream_t st, const uint8_t* src, float* inter, in
     if (static_cast<size_t>(nstrips) * npairs * 4 * C >= (static_cast<size_t>(1) << 30)) return hipErrorInvalidValue;
     const int aligned8 = ((reinterpret_cast<uintptr_t>(src) & 7) == 0 && ((static_cast<size_t>(cols) * 3) & 7) == 0) ? 1 : 0;
     const int grid = wr_balanced_grid(nunits, num_cus);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, src, inter, rows, cols, pad, npairs, nstrips, nunits, aligned8, w256, tw0, mult);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, src, inter, rows, cols, pad, npairs, nstrips, nunits, aligned8, w256, tw0, mult, term);
     return hipGetLastError();
 }
 
 template <int R0, int T>
 hipError_t wr_launch_row_u8(hipStream_t st, const float* inter, uint8_t* dst, int rows, int cols, int pad, int nframes, int num_cus,
-                            const float2* w256, const float2* tw0, const float* mult)
+                            const float2* w256, const float2* tw0, const float* mult, WrRowTile tile)
 {
     if (cols + 2 * pad > R0 * kWrS || pad > cols - 1) return hipErrorInvalidValue;
     const size_t lds = wr_row_lds<R0>(cols);
     const int elo = (pad + kWrS - 1) / kWrS, ehi = R0 - (pad + cols) / kWrS;
     auto kern = (elo <= 1 && ehi <= 1) ? wr_rowpass_u8<R0, T, 1, 1> : wr_rowpass_u8<R0, T, R0, 0>;
     if (hipError_t e = wr_set_lds(kern, lds); e != hipSuccess) return e;
-    const int nstrips = (cols + 7) / 8, npairs = wr_npairs(rows, pad), nunits = npairs * nframes;
-    if (static_cast<size_t>(nstrips) * npairs * 16 >= (static_cast<size_t>(1) << 30)) return hipErrorInvalidValue;
+    // (a band of a tiled image: the rows pair up by the COLUMN call's padding, tile.ypar)
+    const int nstrips = (cols + 7) / 8, npairs = tile.ypar < 0 ? wr_npairs(rows, pad) : ((rows - 1 + tile.ypar) >> 1) + 1, nunits = npairs * nframes;
+    if (static_cast<size_t>(tile.plane_strips > 0 ? tile.plane_strips : nstrips) * npairs * 16 >= (static_cast<size_t>(1) << 30)) return hipErrorInvalidValue;
     const int aligned16 = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && ((static_cast<size_t>(cols) * 3) & 15) == 0) ? 1 : 0;
     const int grid = wr_balanced_grid(nunits, num_cus);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, inter, dst, rows, cols, pad, npairs, nstrips, nunits, aligned16, w256, tw0, mult);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, inter, dst, rows, cols, pad, npairs, nstrips, nunits, aligned16, w256, tw0, mult, tile);
     return hipGetLastError();
 }
 

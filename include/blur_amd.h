@@ -74,7 +74,10 @@ typedef struct blur_opts {
     int row_major_planes;
     /* which kernels run the u8c3 blur: one of enum blur_engine; 0 = the library's choice */
     int engine;
-    int reserved[2];   /* must be zero */
+    /* tests: > 0 forces the tiled wave-resident path (bands of rows / tiles of columns through the wave-resident kernels, the quirk
+       as rank-one terms) with no transform longer than this many points; 0 = the library decides (lines too long for one transform) */
+    int tile_points;
+    int reserved[1];   /* must be zero */
 } blur_opts;
 
 void blur_opts_default(blur_opts* o);
