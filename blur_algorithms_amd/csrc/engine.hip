@@ -1434,7 +1434,8 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
             small_fft = fc.wr_pays || fc.old_both;
         }
     }
-    if (allow_fast && allow_wr && (choice == BLUR_ENGINE_FUSED || choice == BLUR_ENGINE_AUTO)) {
+    const bool force_tiled = opts && opts->tile_points > 0;       // (tests: straight to the tiled wave-resident path)
+    if (!force_tiled && allow_fast && allow_wr && (choice == BLUR_ENGINE_FUSED || choice == BLUR_ENGINE_AUTO)) {
         const FxEntry* fe = find_fx_entry(p.sz.pad);
         // the one-channel-per-workgroup kernels for wide windows (fw_kernels.hpp; measured against the two-kernel engine / the FFT
         // kernels, GP/s: 4K sigma 30 single frame 61 / 50 / 57, eight frames 98 / 85 / 70; 8K sigma 40 single 79 / 54 / 26;
@@ -1465,7 +1466,7 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
             }
         }
     }
-    if (allow_fast && allow_wr && !small_fft && (choice == 0 || choice == 3)) {
+    if (!force_tiled && allow_fast && allow_wr && !small_fft && (choice == 0 || choice == 3)) {
         const MxEntry* me = find_mx_entry(p.sz.pad);
         const int vpitch = (3 * cols + 31) & ~31;
         const bool fits = me && static_cast<long long>(mx_vrows(rows, me->nkb)) * vpitch < (1ll << 30) && static_cast<long long>(rows) * cols * 3 < (1ll << 32);
