@@ -241,12 +241,22 @@ __global__ __launch_bounds__(256) void tl_terms_kernel(const int* __restrict__ s
     if (static_cast<int>(blockIdx.x) < ne) {
         const int x = blockIdx.x * 256 + tid;
         if (x >= pitch) return;
-        for (int c = 0; c < 3; ++c) {
-            long long sum = 0;
-            if (x < cols)
-                for (int b = 0; b < nbands; ++b) sum += cpart[(static_cast<size_t>(f) * nbands + b) * cpitch + 3 * x + c];
-            e[(static_cast<size_t>(f) * 3 + c) * pitch + x] = static_cast<float>(static_cast<double>(dc) * static_cast<double>(sum));
+        // the bands' parts in batches of eight independent loads per channel (a band's part is below 2^31 / nbands: exact in int)
+        const int* cp = cpart + static_cast<size_t>(f) * nbands * cpitch + 3 * (x < cols ? x : 0);
+        long long tot[3] = { 0, 0, 0 };
+        for (int b0 = 0; b0 < nbands; b0 += 8) {
+            int t[8][3];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) t[j][c] = cp[static_cast<size_t>(b0 + j < nbands ? b0 + j : nbands - 1) * cpitch + c];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) tot[c] += b0 + j < nbands ? t[j][c] : 0;
         }
+        for (int c = 0; c < 3; ++c)
+            e[(static_cast<size_t>(f) * 3 + c) * pitch + x] = x < cols ? static_cast<float>(static_cast<double>(dc) * static_cast<double>(tot[c])) : 0.f;
         return;
     }
     const int r0 = (blockIdx.x - ne) * 256, win = 256 + 2 * pad, ntap = 2 * pad + 1;
@@ -1240,7 +1250,7 @@ static FftFamilyChoice fft_family_choice(int rows, int cols, const Sizing& sz)
 // The first and the last span end at an image border and are padded by the kernel itself (reflect-101, padmode = pad: in + 2 pad
 // points); the spans between are circular convolutions of real pixels only (padmode = 0: in points) whose first `halo` (= pad rounded
 // up to `align`, so that the kept part starts at a multiple of `align`) and last pad results are not kept.  False: pad too wide.
-static bool plan_spans(int len, int pad, int nmax, int in_max, int align, std::vector<Prepared::Span>& out)
+static bool plan_spans(int len, int pad, int nmax, int in_max, int align, std::vector<Prepared::Span>& out, bool equal_middle = false)
 {
     out.clear();
     if (in_max > nmax) in_max = nmax;
@@ -1253,7 +1263,7 @@ static bool plan_spans(int len, int pad, int nmax, int in_max, int align, std::v
     int nsp0 = 2;
     if (len > 2 * ve) nsp0 += (len - 2 * ve + vm - 1) / vm;
     std::vector<int> b;
-    int nsp = 0;
+    int nsp = 0, sm_equal = 0;
     for (int tries = 0; tries < 4 && nsp == 0; ++tries) {
         const int n = nsp0 + tries;
         b.assign(n + 1, 0);
@@ -1264,6 +1274,19 @@ static bool plan_spans(int len, int pad, int nmax, int in_max, int align, std::v
         if (e < align) e = align;
         b[1] = e;
         const int rest = len - 2 * e;
+        if (equal_middle && n > 2) {
+            // middle spans of ONE length (a multiple of 2 and of align), so that they can run as the "frames" of one launch; the last of
+            // them may reach into the last span's rows (written twice, by both)
+            const int unit = align % 2 == 0 ? align : 2 * align;
+            const int sm = ((rest + (n - 2) - 1) / (n - 2) + unit - 1) / unit * unit;
+            if (sm > vm || e + (n - 2) * sm + pad > len) continue;
+            for (int i = 2; i < n; ++i) b[i] = e + (i - 1) * sm;
+            b[n - 1] = len - e;                                                               // the last span keeps its own e lines
+            if (b[n - 1] <= b[n - 2] - sm) continue;
+            nsp = n;
+            sm_equal = sm;
+            break;
+        }
         for (int i = 2; i < n; ++i) b[i] = (e + static_cast<int>(static_cast<long long>(rest) * (i - 1) / (n - 2))) / align * align;
         b[n - 1] = std::max(b[n - 1], (len - ve + align - 1) / align * align);             // the last span's limit
         bool ok = len - b[n - 1] <= ve && len - b[n - 1] > 0 && b[1] <= ve;
@@ -1278,7 +1301,10 @@ static bool plan_spans(int len, int pad, int nmax, int in_max, int align, std::v
         sp.v1 = b[i + 1];
         if (i == 0) { sp.in0 = 0; sp.in1 = std::min(len, sp.v1 + pad); sp.padmode = pad; }
         else if (i == nsp - 1) { sp.in0 = sp.v0 - halo; sp.in1 = len; sp.padmode = pad; }
-        else { sp.in0 = sp.v0 - halo; sp.in1 = std::min(len, sp.v1 + pad); sp.padmode = 0; }
+        else {
+            if (sm_equal > 0) sp.v1 = sp.v0 + sm_equal;            // (the last middle span may reach into the last span's lines)
+            sp.in0 = sp.v0 - halo; sp.in1 = std::min(len, sp.v1 + pad); sp.padmode = 0;
+        }
         if (sp.in0 < 0 || sp.in1 - sp.in0 + 2 * sp.padmode > nmax || sp.in1 - sp.in0 > in_max || sp.padmode > sp.in1 - sp.in0 - 1) return false;
         out.push_back(sp);
     }
@@ -1309,7 +1335,7 @@ static int plan_tiled(blur_ctx* ctx, int rows, int cols, double sigma, bool quir
         int in_max = n;
         while (in_max > 0 && e->col_lds(in_max) > kLdsLimit) in_max -= 8;
         std::vector<Prepared::Span> sp;
-        if (in_max <= 0 || !plan_spans(rows, pad, n, in_max, 1, sp)) continue;
+        if (in_max <= 0 || !plan_spans(rows, pad, n, in_max, 1, sp, true)) continue;
         const long long cost = static_cast<long long>(sp.size()) * n;
         if (best < 0 || cost < best) { best = cost; p.bands = sp; p.tl_col = e; }
     }
@@ -2016,8 +2042,6 @@ static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int
 {
     const size_t px = static_cast<size_t>(rows) * cols, fb = px * 3;
     const int pad = p.sz.pad;
-    if (int rc = ensure_work(ctx, p.frame_elems * sizeof(float))) return rc;
-    float* const inter = reinterpret_cast<float*>(ctx->work);
     const int groups = (cols + 3) / 4, gpt = fx_groups_per_thread(cols);
     if (p.tl_quirk && (gpt == 0 || cols < 4)) return fail(ctx, BLUR_ERR_UNSUPPORTED, "tiled wave-resident path: image width outside 4 .. 16384 (the quirk's pre-pass)");
     const int pitch = (cols + 7) & ~7;
@@ -2027,6 +2051,7 @@ static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int
     int band_rows = 0, nbands = 0, nbatches = 0;
     if (p.tl_quirk) {
         band_rows = fx_band_rows(rows, cols, 1, ctx->num_cus);
+        while (band_rows < 256 && (rows + band_rows - 1) / band_rows > 64) band_rows *= 2;       // the term kernel adds up the bands' parts per column
         nbands = (rows + band_rows - 1) / band_rows;
         nbatches = (groups + 256 * gpt - 1) / (256 * gpt);
         auto up4 = [](size_t v) { return (v + 3) & ~static_cast<size_t>(3); };
@@ -2078,16 +2103,50 @@ static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int
                                12 * groups, p.tl_dr, p.tl_dc, ne);
             HIP_TRY(ctx, hipGetLastError());
         }
-        for (const Prepared::Span& b : p.bands) {
+        // consecutive middle bands of one shape, a constant (even) number of rows apart, are the "frames" of ONE launch per kernel
+        auto group_of = [&](size_t bi, int& step) -> int {
+            const Prepared::Span& b = p.bands[bi];
             const int brows = b.in1 - b.in0;
+            int nb = 1;
+            step = 0;
+            if (b.padmode == 0) {
+                while (bi + nb < p.bands.size()) {
+                    const Prepared::Span& c = p.bands[bi + nb];
+                    const int st = c.in0 - p.bands[bi + nb - 1].in0;
+                    if (c.padmode != 0 || c.in1 - c.in0 != brows || c.v0 - c.in0 != b.v0 - b.in0 || c.v1 - c.v0 != b.v1 - b.v0 || (st & 1) || (nb > 1 && st != step)) break;
+                    step = st;
+                    ++nb;
+                }
+            }
+            if (nb > 1 && wr_frame_floats(brows, cols, b.padmode) * nb * sizeof(float) > (static_cast<size_t>(3) << 30)) { nb = 1; step = 0; }
+            return nb;
+        };
+        {
+            size_t need = 0;
+            for (size_t bi = 0; bi < p.bands.size();) {
+                int step;
+                const int nb = group_of(bi, step);
+                need = std::max(need, wr_frame_floats(p.bands[bi].in1 - p.bands[bi].in0, cols, p.bands[bi].padmode) * nb * sizeof(float));
+                bi += nb;
+            }
+            if (int rc = ensure_work(ctx, need)) return rc;
+        }
+        float* const inter = reinterpret_cast<float*>(ctx->work);
+        for (size_t bi = 0; bi < p.bands.size();) {
+            const Prepared::Span& b = p.bands[bi];
+            const int brows = b.in1 - b.in0;
+            int step = 0;
+            const int nb = group_of(bi, step);
+            const int vr_max = bi + nb < p.bands.size() ? p.bands[bi + nb].v0 : rows;       // rows from here on are the next band's
             WrColTerm term;
             if (p.tl_quirk) {
                 term.e = e;
                 term.pitch = pitch;
                 term.sign = ((b.in0 + pad - b.padmode) & 1) ? -1.f : 1.f;       // (-1)^(image row + pad) of slot 0: slot = (band row + padmode) & 1
             }
+            term.band_step = nb > 1 ? step : 0;
             { TimedLaunch t(ctx, 1, 1);
-              HIP_TRY(ctx, p.tl_col->col_u8(ctx->stream, src + static_cast<size_t>(b.in0) * cols * 3, inter, brows, cols, b.padmode, 1, ctx->num_cus, ctx->d_w256, p.tl_tw0_col,
+              HIP_TRY(ctx, p.tl_col->col_u8(ctx->stream, src + static_cast<size_t>(b.in0) * cols * 3, inter, brows, cols, b.padmode, nb, ctx->num_cus, ctx->d_w256, p.tl_tw0_col,
                                             p.tl_m_col, term)); }
             const int npairs = wr_npairs(brows, b.padmode), strips_full = (cols + 7) / 8;
             for (size_t ti = 0; ti < p.tiles.size(); ++ti) {
@@ -2105,10 +2164,16 @@ static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int
                 tile.vc1 = t.v1 - t.in0;
                 tile.xpar = (t.in0 + pad) & 1;                                   // (-1)^(image column + pad): the call's column 0 is image column in0
                 tile.plane_strips = strips_full;
+                tile.t0 = (b.v0 - b.in0 + tile.ypar) >> 1;                        // the pairs that hold a kept row
+                tile.tn = ((b.v1 - 1 - b.in0 + tile.ypar) >> 1) - tile.t0 + 1;
+                tile.band_step = nb > 1 ? step : 0;
+                tile.vr_max = vr_max;
+                if (nb == 1 && tile.vr1 > vr_max) tile.vr1 = vr_max;
                 TimedLaunch tl(ctx, 0, 1);
-                HIP_TRY(ctx, p.tl_row[ti]->row_u8(ctx->stream, inter + static_cast<size_t>(t.in0 / 8) * npairs * 16, dst, brows, t.in1 - t.in0, t.padmode, 1, ctx->num_cus,
+                HIP_TRY(ctx, p.tl_row[ti]->row_u8(ctx->stream, inter + static_cast<size_t>(t.in0 / 8) * npairs * 16, dst, brows, t.in1 - t.in0, t.padmode, nb, ctx->num_cus,
                                                   ctx->d_w256, p.tl_tw0_row[ti], p.tl_m_row[ti], tile));
             }
+            bi += nb;
         }
     }
     return BLUR_OK;

@@ -338,6 +338,7 @@ struct WrColTerm {
     const float* e = nullptr;      // [frame][channel][pitch]: e(x) per column (nullptr: no term)
     int pitch = 0;                 // floats per (frame, channel): the image width rounded up to 8
     float sign = 1.f;              // (-1)^(r + pad) of slot 0 of a row pair of this call
+    int band_step = 0;             // > 0: the call's "frames" are bands of ONE image, band_step (even) image rows apart
 };
 // what a row-pass call on a band / tile needs beyond the plain call (defaults = the whole image)
 struct WrRowTile {
@@ -351,6 +352,9 @@ struct WrRowTile {
     int vc0 = 0, vc1 = 0;          // columns [vc0, vc1) of the call are written (vc1 = 0: all); vc0 a multiple of 16
     int xpar = 0;                  // parity of (image column of the call's column 0 + the kernel's half width): sign of h's term
     int plane_strips = 0;          // strips of 8 columns per channel plane of the intermediate (0: the call's)
+    int t0 = 0, tn = 0;            // row pairs [t0, t0 + tn) of a frame are transformed (tn = 0: all): the others hold no row that is written
+    int band_step = 0;             // > 0: the call's "frames" are bands of ONE image, band_step image rows apart (row_base, vr0, vr1 of band 0)
+    int vr_max = 0;                // band_step > 0: no image row from vr_max on is written (the last band may reach into the next span's rows)
 };
 
 // ELO / EHI: the first ELO and the last EHI rounds k of pass 0 may touch the reflected borders or the zero tail (index
@@ -392,7 +396,7 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
     constexpr int KP = (KU + 2) / 3;                  // pieces per task
     typedef unsigned int wr_u32x2 __attribute__((ext_vector_type(2)));
     wr_u32x2 pfu[KU];
-    const size_t frame_bytes = static_cast<size_t>(rows) * cols * CH;
+    const size_t frame_bytes = static_cast<size_t>(term.band_step > 0 ? term.band_step : rows) * cols * CH;     // bands of one image overlap in memory
     const int npiece = rows * PIECES;
     auto strip_fast = [&](int uu) { const int ss = uu % nstrips; return aligned8 != 0 && (ss + 1) * G <= cols; };
     // pieces [k0, k1) of strip uu
@@ -489,7 +493,7 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
         for (int it = 0; it < IT0; ++it) {
             const int g = tid + T * it;
             const int x = strip_ * G + 2 * line_of(g) + (bfly_of(g) & 1);
-            tv[it] = term.sign * term.e[(static_cast<size_t>(ff) * CH + ch_) * term.pitch + (x < term.pitch ? x : 0)];
+            tv[it] = term.sign * term.e[(static_cast<size_t>(term.band_step > 0 ? 0 : ff) * CH + ch_) * term.pitch + (x < term.pitch ? x : 0)];
         }
     };
     // inverse pass 0 of the task whose output block is `out_blk`: LDS -> butterfly -> lane-pair exchange -> global
@@ -651,8 +655,9 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
 
     typedef float wr_f32x2 __attribute__((ext_vector_type(2)));
     wr_f32x2 pf[R0];
+    const int upf = tile.tn > 0 ? tile.tn : npairs;             // units (row pairs) per frame
     auto unit_base = [&](int uu) -> const char* {
-        const int ff = uu / npairs, tt = uu - ff * npairs;
+        const int ff = uu / upf, tt = uu - ff * upf + tile.t0;
         return reinterpret_cast<const char*>(inter + (static_cast<size_t>(ff) * CH + c) * plane + static_cast<size_t>(tt) * (2 * G));
     };
     // rounds [k0, k1) of the unit whose (channel, pair) records start at `base`
@@ -683,10 +688,10 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
     const float sxf = ((jm + tile.xpar) & 1) ? -1.f : 1.f;       // (256 k is even: one sign per thread)
     auto half_of = [&](int uu, int slot) -> float {
         if (tile.h == nullptr) return 0.5f;                      // uniform
-        const int ff = uu / npairs, tt = uu - ff * npairs;
-        int r = tile.row_base + 2 * tt - ypar + slot;
+        const int ff = uu / upf, tt = uu - ff * upf + tile.t0;
+        int r = tile.row_base + ff * tile.band_step + 2 * tt - ypar + slot;
         r = r < 0 ? 0 : (r >= rows_out ? rows_out - 1 : r);
-        return 0.5f + sxf * tile.h[(static_cast<size_t>(ff) * CH + c) * rows_out + r];
+        return 0.5f + sxf * tile.h[(static_cast<size_t>(tile.band_step > 0 ? 0 : ff) * CH + c) * rows_out + r];
     };
     // inverse pass 0 of the unit in `lines` -> "+0.5f, truncate" -> byte stage
     auto inverse_pass0 = [&](int uu) {
@@ -711,14 +716,18 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
         if (tile.vr1 > 0 || tile.vc1 > 0 || tile.dst_pitch > 0) {
             // a band / tile of a larger image: image rows [vr0, vr1) and the call's columns [vc0, vc1) only, rows dst_pitch apart;
             // 16-byte pieces from the (aligned) stage to wherever they belong, then the odd bytes
-            const int vr1 = tile.vr1 > 0 ? tile.vr1 : tile.row_base + rows, vc1 = tile.vc1 > 0 ? tile.vc1 : cols;
+            const int bofs = f * tile.band_step;                  // this band's offset in image rows (0: frames are images)
+            int vr1 = (tile.vr1 > 0 ? tile.vr1 : tile.row_base + rows) + bofs;
+            if (tile.band_step > 0 && tile.vr_max > 0 && vr1 > tile.vr_max) vr1 = tile.vr_max;
+            const int vr0 = tile.vr0 + bofs, vc1 = tile.vc1 > 0 ? tile.vc1 : cols;
             const size_t pitch = tile.dst_pitch > 0 ? static_cast<size_t>(tile.dst_pitch) : static_cast<size_t>(rowbytes);
-            const int g0 = tile.row_base + 2 * t - ypar;         // image row of slot 0
+            const int g0 = tile.row_base + bofs + 2 * t - ypar;  // image row of slot 0
+            const int fimg = tile.band_step > 0 ? 0 : f;
             const int nb = (vc1 - tile.vc0) * CH, n16 = nb >> 4;
             for (int rb = 0; rb < 2; ++rb) {
                 const int gr = g0 + rb;
-                if (gr < tile.vr0 || gr >= vr1) continue;       // uniform
-                uint8_t* const o = dst + (static_cast<size_t>(f) * rows_out + gr) * pitch + static_cast<size_t>(tile.dst_x0 + tile.vc0) * CH;
+                if (gr < vr0 || gr >= vr1) continue;            // uniform
+                uint8_t* const o = dst + (static_cast<size_t>(fimg) * rows_out + gr) * pitch + static_cast<size_t>(tile.dst_x0 + tile.vc0) * CH;
                 const uint8_t* const sp = stage + rb * stage_row + tile.vc0 * CH;
                 typedef unsigned int wr_u32x4 __attribute__((ext_vector_type(4), aligned(1)));
                 for (int i = tid; i < n16; i += T) {
@@ -782,7 +791,7 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
         WR_STAMP(1);
         // ---- phase B: write-out of the previous unit (the stage is complete), middle of this one
 #ifndef WR_ROW_STORE_LATE
-        if (pu >= 0) write_out(pu / npairs, pu % npairs);
+        if (pu >= 0) write_out(pu / upf, pu % upf + tile.t0);
 #endif
         WR_STAMP(6);      // write-out
         // the next unit's input is requested a quarter at a time from inside the middle section
@@ -792,7 +801,7 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
         if (WR_MID_ON(mid_on)) wr_middle(lines + wr_opaque(sbi) * kWrSB, wm, wr_opaque(lane16), hook);
         else { hook(0, 0.f); hook(1, 0.f); hook(2, 0.f); hook(3, 0.f); }
 #ifdef WR_ROW_STORE_LATE
-        if (pu >= 0) write_out(pu / npairs, pu % npairs);      // behind the requests for the next unit's rows
+        if (pu >= 0) write_out(pu / upf, pu % upf + tile.t0);      // behind the requests for the next unit's rows
 #endif
         WR_STAMP(2);      // middle
         // (no wait for the requested rows here: the barrier must not wait on memory latency.  Nothing else is issued to
@@ -804,7 +813,7 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
     if (pu >= 0) {
         inverse_pass0(pu);
         __syncthreads();
-        write_out(pu / npairs, pu % npairs);
+        write_out(pu / upf, pu % upf + tile.t0);
     }
     WR_STAMP_FLUSH(mult, R0 * kWrS, T / 64);
 }
@@ -907,7 +916,8 @@ hipError_t wr_launch_col_u8(hipStream_t st, const uint8_t* src, float* inter, in
     const int nstrips = (cols + 2 * C - 1) / (2 * C), npairs = wr_npairs(rows, pad), nunits = nstrips * nframes;
     // 32-bit float offsets inside a channel plane
     if (static_cast<size_t>(nstrips) * npairs * 4 * C >= (static_cast<size_t>(1) << 30)) return hipErrorInvalidValue;
-    const int aligned8 = ((reinterpret_cast<uintptr_t>(src) & 7) == 0 && ((static_cast<size_t>(cols) * 3) & 7) == 0) ? 1 : 0;
+    // (the strip's 8-byte pieces may sit at any byte address: gfx950 takes unaligned vector loads; only a ragged last strip goes byte by byte)
+    const int aligned8 = 1;
     const int grid = wr_balanced_grid(nunits, num_cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, src, inter, rows, cols, pad, npairs, nstrips, nunits, aligned8, w256, tw0, mult, term);
     return hipGetLastError();
@@ -923,7 +933,9 @@ hipError_t wr_launch_row_u8(hipStream_t st, const float* inter, uint8_t* dst, in
     auto kern = (elo <= 1 && ehi <= 1) ? wr_rowpass_u8<R0, T, 1, 1> : wr_rowpass_u8<R0, T, R0, 0>;
     if (hipError_t e = wr_set_lds(kern, lds); e != hipSuccess) return e;
     // (a band of a tiled image: the rows pair up by the COLUMN call's padding, tile.ypar)
-    const int nstrips = (cols + 7) / 8, npairs = tile.ypar < 0 ? wr_npairs(rows, pad) : ((rows - 1 + tile.ypar) >> 1) + 1, nunits = npairs * nframes;
+    const int nstrips = (cols + 7) / 8, npairs = tile.ypar < 0 ? wr_npairs(rows, pad) : ((rows - 1 + tile.ypar) >> 1) + 1;
+    if (tile.tn > 0 && (tile.t0 < 0 || tile.t0 + tile.tn > npairs)) return hipErrorInvalidValue;
+    const int nunits = (tile.tn > 0 ? tile.tn : npairs) * nframes;
     if (static_cast<size_t>(tile.plane_strips > 0 ? tile.plane_strips : nstrips) * npairs * 16 >= (static_cast<size_t>(1) << 30)) return hipErrorInvalidValue;
     const int aligned16 = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && ((static_cast<size_t>(cols) * 3) & 15) == 0) ? 1 : 0;
     const int grid = wr_balanced_grid(nunits, num_cus);

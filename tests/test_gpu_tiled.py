@@ -18,7 +18,9 @@ def _rand_img(rows, cols, seed):
 # (rows, cols, sigma, tile_points): transforms of 768 / 1024 / 1280 points on images of several bands and tiles; widths that are no
 # multiples of 16 or 8; a pad of odd and of even parity; one band but several tiles and the other way round
 FORCED = [(900, 700, 20.0, 768), (901, 733, 20.0, 768), (1300, 520, 12.0, 768), (420, 1500, 12.5, 768), (700, 900, 30.0, 1024), (1000, 1010, 25.0, 1280),
-          (640, 2100, 9.0, 768), (2000, 300, 21.0, 1024), (555, 777, 19.5, 1536)]
+          (640, 2100, 9.0, 768), (2000, 300, 21.0, 1024), (555, 777, 19.5, 1536),
+          # several middle bands of one shape: they run as the "frames" of one launch per kernel
+          (2600, 200, 12.0, 768), (3301, 136, 10.0, 768), (2900, 1400, 20.0, 1024)]
 
 
 @pytest.mark.parametrize("rows,cols,sigma,points", FORCED)
