@@ -281,7 +281,15 @@ def reference_sweep(args, torch, B):
             torch.cuda.synchronize(dev)
             ms = e0.elapsed_time(e1) / n
             fam = lib.blur_debug_last_family(ctx._h)
-            gen = ctx.pffft_(img, sigma, out=torch.empty_like(img), force_generic=True)
+            gen_out = torch.empty_like(img)
+            gen = ctx.pffft_(img, sigma, out=gen_out, force_generic=True)
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for _ in range(2):
+                ctx.pffft_(img, sigma, out=gen_out, force_generic=True)
+            g1.record()
+            torch.cuda.synchronize(dev)
+            rec["generic_ms"] = round(g0.elapsed_time(g1) / 2, 4)          # the run-time-planned FFT kernels on the same image, for comparison
             d = (out.to(torch.int16) - gen.to(torch.int16))
             d = (d + 128) % 256 - 128
             rec.update({"ms": round(ms, 4), "megapixels_per_s": round(rows * cols / 1e6 / (ms * 1e-3), 1),

@@ -1250,7 +1250,7 @@ static FftFamilyChoice fft_family_choice(int rows, int cols, const Sizing& sz)
 // The first and the last span end at an image border and are padded by the kernel itself (reflect-101, padmode = pad: in + 2 pad
 // points); the spans between are circular convolutions of real pixels only (padmode = 0: in points) whose first `halo` (= pad rounded
 // up to `align`, so that the kept part starts at a multiple of `align`) and last pad results are not kept.  False: pad too wide.
-static bool plan_spans(int len, int pad, int nmax, int in_max, int align, std::vector<Prepared::Span>& out, bool equal_middle = false)
+static bool plan_spans(int len, int pad, int nmax, int in_max, int align, std::vector<Prepared::Span>& out, bool equal_middle = false, bool edge_max = false)
 {
     out.clear();
     if (in_max > nmax) in_max = nmax;
@@ -1269,8 +1269,9 @@ static bool plan_spans(int len, int pad, int nmax, int in_max, int align, std::v
         b.assign(n + 1, 0);
         b[n] = len;
         // edge spans take the same share as the middle ones where that fits their limit
-        int e = static_cast<int>(static_cast<long long>(len) / n) / align * align;
+        int e = edge_max ? ve : static_cast<int>(static_cast<long long>(len) / n) / align * align;      // (edge_max: the edge spans as long as they go)
         if (e > ve) e = ve;
+        if (2 * e >= len) e = (len / 2) / align * align;
         if (e < align) e = align;
         b[1] = e;
         const int rest = len - 2 * e;
@@ -1348,10 +1349,18 @@ static int plan_tiled(blur_ctx* ctx, int rows, int cols, double sigma, bool quir
         if (!e || e->r0 != r0) continue;
         int in_max = n;
         while (in_max > 0 && e->row_lds(in_max) > kLdsLimit) in_max -= 16;
-        std::vector<Prepared::Span> sp;
-        if (in_max <= 0 || !plan_spans(cols, pad, n, in_max, 16, sp)) continue;
-        const long long cost = static_cast<long long>(sp.size()) * n;
-        if (best < 0 || cost < best) { best = cost; p.tiles = sp; }
+        if (in_max <= 0) continue;
+        for (int variant = 0; variant < 2; ++variant) {
+            std::vector<Prepared::Span> sp;
+            if (!plan_spans(cols, pad, n, in_max, 16, sp, false, variant == 1)) continue;
+            // every tile runs on the smallest kernel that holds it: the cost is the transform points per row
+            long long cost = 0;
+            for (const Prepared::Span& t : sp) {
+                const WrEntry* te = find_wr_entry(t.in1 - t.in0 + 2 * t.padmode, false);
+                cost += te ? te->r0 * kWrS : 1 << 20;
+            }
+            if (best < 0 || cost < best) { best = cost; p.tiles = sp; }
+        }
     }
     if (best < 0) return BLUR_ERR_UNSUPPORTED;
     uint64_t bits;
@@ -2042,16 +2051,18 @@ static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int
 {
     const size_t px = static_cast<size_t>(rows) * cols, fb = px * 3;
     const int pad = p.sz.pad;
-    const int groups = (cols + 3) / 4, gpt = fx_groups_per_thread(cols);
-    if (p.tl_quirk && (gpt == 0 || cols < 4)) return fail(ctx, BLUR_ERR_UNSUPPORTED, "tiled wave-resident path: image width outside 4 .. 16384 (the quirk's pre-pass)");
+    // (the pre-pass with one group of 4 pixels per thread: the term kernel adds up any number of batch parts, unlike the fused kernel)
+    const int groups = (cols + 3) / 4, gpt = 1;
+    if (p.tl_quirk && cols < 4) return fail(ctx, BLUR_ERR_UNSUPPORTED, "tiled wave-resident path: image narrower than 4 pixels (the quirk's pre-pass)");
     const int pitch = (cols + 7) & ~7;
     int *srow = nullptr, *cpart = nullptr;
     long long* zpart = nullptr;
     float *e = nullptr, *h = nullptr;
     int band_rows = 0, nbands = 0, nbatches = 0;
     if (p.tl_quirk) {
-        band_rows = fx_band_rows(rows, cols, 1, ctx->num_cus);
-        while (band_rows < 256 && (rows + band_rows - 1) / band_rows > 64) band_rows *= 2;       // the term kernel adds up the bands' parts per column
+        // bands as tall as still give four workgroups per CU: the term kernel adds up the bands' parts per column
+        band_rows = static_cast<long long>(rows) * cols < 4000000ll ? 16 : kFxSumRows;
+        while (band_rows < 256 && static_cast<long long>((groups + 255) / 256) * ((rows + 2 * band_rows - 1) / (2 * band_rows)) >= 4ll * ctx->num_cus) band_rows *= 2;
         nbands = (rows + band_rows - 1) / band_rows;
         nbatches = (groups + 256 * gpt - 1) / (256 * gpt);
         auto up4 = [](size_t v) { return (v + 3) & ~static_cast<size_t>(3); };
@@ -2093,8 +2104,7 @@ static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int
         if (p.tl_quirk) {
             TimedLaunch t(ctx, 1, 1);
             const int n_alt = nbands * nbatches;
-            auto kern = gpt == 1 ? fx_prepass<1> : (gpt == 2 ? fx_prepass<2> : fx_prepass<4>);
-            hipLaunchKernelGGL(kern, dim3(n_alt), dim3(256), 0, ctx->stream, src, srow, cpart, zpart, nullptr, rows, cols, pad, 0, nbands, nbatches, n_alt, 1, 0, 1, band_rows);
+            hipLaunchKernelGGL(fx_prepass<1>, dim3(n_alt), dim3(256), 0, ctx->stream, src, srow, cpart, zpart, nullptr, rows, cols, pad, 0, nbands, nbatches, n_alt, 1, 0, 1, band_rows);
             HIP_TRY(ctx, hipGetLastError());
             const int ne = (pitch + 255) / 256, nh = (rows + 255) / 256;
             const size_t lds = (static_cast<size_t>(3) * (256 + 2 * pad) + (2 * pad + 1) + 3 + 3 * 256) * sizeof(double);

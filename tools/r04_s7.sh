@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/s7; rm -rf $O; mkdir -p $O
-for sh in "11400 7600 106.77" "6000 4000 77.46"; do
+for sh in "2625 1750 51.23" "4425 2950 66.52" "11400 7600 106.77"; do
   set -- $sh
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/k_$1 -- python3 $GRAFT_REPO_ROOT/tools/one_shape.py $1 $2 $3 1 > $O/k_$1.log 2>&1
   tail -1 $O/k_$1.log

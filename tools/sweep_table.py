@@ -10,5 +10,6 @@ for x in r["sizes"]:
     if "ms" not in x:
         print("  %5dx%-5d %s" % (x["rows"], x["cols"], x.get("error")))
         continue
-    print("  %5dx%-5d s=%6.1f N1/N0 %5d/%-5d %8.3f ms %9.0f MP/s  %-34s diff %d %.1e" % (
-        x["rows"], x["cols"], x["sigma"], x["N1"], x["N0"], x["ms"], x["megapixels_per_s"], x.get("kernels", "?"), x["max_abs_diff_vs_generic"], x["frac_diff_vs_generic"]))
+    print("  %5dx%-5d s=%6.1f N1/N0 %5d/%-5d %8.3f ms %9.0f MP/s  %-34s diff %d %.1e%s" % (
+        x["rows"], x["cols"], x["sigma"], x["N1"], x["N0"], x["ms"], x["megapixels_per_s"], x.get("kernels", "?"), x["max_abs_diff_vs_generic"], x["frac_diff_vs_generic"],
+        "   (run-time-planned kernels: %.3f ms)" % x["generic_ms"] if "generic_ms" in x else ""))
