@@ -6,7 +6,7 @@ R=$1
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
 rm -rf $OUT; mkdir -p $OUT
-B="$GRAFT_REPO_ROOT/bench.py --no-cpu --no-natural --no-copy $BENCH_ARGS"
+B="$GRAFT_REPO_ROOT/bench.py --no-cpu --no-natural --no-copy --no-configs $BENCH_ARGS"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $B --steps 10 --warmup 3 > $OUT/bench_under_rocprof.log 2>&1
 pmc() { # name counters...
   local name=$1; shift
