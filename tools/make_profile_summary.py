@@ -89,7 +89,7 @@ for k in sorted(summary):
             "fetch_size_raw_bytes": fetch, "fetch_correction": f, "write_size_bytes": write,
             "hbm_bytes_per_launch": fetch * f + write,
             # two-pass kernels: 15 B/px each; the fused kernel has to move 6 B/px (3 in + 3 out), its pre-pass 3 B/px
-            "alg_bytes_per_launch": ({"fx_blur_u8": 6, "fx_altsums": 3}.get(k, 15) * px * frames_per_launch) if not k.startswith("fx_") or k in ("fx_blur_u8", "fx_altsums") else None,
+            "alg_bytes_per_launch": ({"fx_blur_u8": 6, "fx_altsums": 3, "fx_prepass": 3}.get(k, 15) * px * frames_per_launch) if not k.startswith("fx_") or k in ("fx_blur_u8", "fx_altsums", "fx_prepass") else None,
             "l2_hit_rate": round(summary[k]["TCC_HIT_sum"] / (summary[k]["TCC_HIT_sum"] + summary[k]["TCC_MISS_sum"]), 4) if "TCC_HIT_sum" in summary[k] else None,
             "source": "%s_pmc_counters.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / TCC_HIT_sum TCC_MISS_sum, separate runs of bench.py)" % tag,
         }
