@@ -1328,7 +1328,7 @@ static int plan_tiled(blur_ctx* ctx, int rows, int cols, double sigma, bool quir
     const int pad = p.sz.pad;
     // one column kernel for all bands: the candidate that transforms the fewest points per column
     long long best = -1;
-    for (int r0 : { 10, 9, 8, 6, 5, 4, 3 }) {
+    for (int r0 : { 16, 15, 12, 10, 9, 8, 6, 5, 4, 3 }) {
         const int n = r0 * kWrS;
         if (tile_points > 0 && n > tile_points) continue;
         const WrEntry* e = find_wr_entry(n, true);
@@ -1408,7 +1408,7 @@ static int plan_tiled(blur_ctx* ctx, int rows, int cols, double sigma, bool quir
         p.tl_taps = it->second;
     }
     p.frame_elems = 0;
-    for (const Prepared::Span& b : p.bands) p.frame_elems = std::max(p.frame_elems, wr_frame_floats(b.in1 - b.in0, cols, b.padmode));
+    for (const Prepared::Span& b : p.bands) p.frame_elems = std::max(p.frame_elems, wr_frame_floats(b.in1 - b.in0, cols, b.padmode, p.tl_col->g));
     p.tiled = true;
     p.tl_quirk = quirk;
     return BLUR_OK;
@@ -1546,7 +1546,7 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         const WrEntry* wr = fc.wr;
         const bool pays = (opts && opts->engine == BLUR_ENGINE_FFT_WAVE_RESIDENT) || fc.wr_pays;
         if (fc.fits && pays &&
-            wr_frame_floats(rows, cols, p.sz.pad) / 3 < (static_cast<size_t>(1) << 30)) {
+            wr_frame_floats(rows, cols, p.sz.pad, wc->g) / 3 < (static_cast<size_t>(1) << 30)) {
             if (int rc = wr_get_tables(ctx, wc, &p.wr_tw0_col)) return rc;
             if (int rc = wr_get_tables(ctx, wr, &p.wr_tw0_row)) return rc;
             for (int pass = 0; pass < 2; ++pass) {
@@ -1576,7 +1576,7 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
             }
             p.wr_col = wc;
             p.wr_row = wr;
-            p.frame_elems = wr_frame_floats(rows, cols, p.sz.pad);
+            p.frame_elems = wr_frame_floats(rows, cols, p.sz.pad, wc->g);
             return BLUR_OK;
         }
     }
@@ -2130,7 +2130,7 @@ static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int
                     ++nb;
                 }
             }
-            if (nb > 1 && wr_frame_floats(brows, cols, b.padmode) * nb * sizeof(float) > (static_cast<size_t>(3) << 30)) { nb = 1; step = 0; }
+            if (nb > 1 && wr_frame_floats(brows, cols, b.padmode, p.tl_col->g) * nb * sizeof(float) > (static_cast<size_t>(3) << 30)) { nb = 1; step = 0; }
             return nb;
         };
         {
@@ -2138,7 +2138,7 @@ static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int
             for (size_t bi = 0; bi < p.bands.size();) {
                 int step;
                 const int nb = group_of(bi, step);
-                need = std::max(need, wr_frame_floats(p.bands[bi].in1 - p.bands[bi].in0, cols, p.bands[bi].padmode) * nb * sizeof(float));
+                need = std::max(need, wr_frame_floats(p.bands[bi].in1 - p.bands[bi].in0, cols, p.bands[bi].padmode, p.tl_col->g) * nb * sizeof(float));
                 bi += nb;
             }
             if (int rc = ensure_work(ctx, need)) return rc;
@@ -2160,7 +2160,7 @@ static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int
             { TimedLaunch t(ctx, 1, 1);
               HIP_TRY(ctx, p.tl_col->col_u8(ctx->stream, src + static_cast<size_t>(b.in0) * cols * 3, inter, brows, cols, b.padmode, nb, ctx->num_cus, ctx->d_w256, p.tl_tw0_col,
                                             p.tl_m_col, term)); }
-            const int npairs = wr_npairs(brows, b.padmode), strips_full = (cols + 7) / 8;
+            const int g = p.tl_col->g, npairs = wr_npairs(brows, b.padmode), strips_full = (cols + g - 1) / g;
             for (size_t ti = 0; ti < p.tiles.size(); ++ti) {
                 const Prepared::Span& t = p.tiles[ti];
                 WrRowTile tile;
@@ -2176,13 +2176,14 @@ static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int
                 tile.vc1 = t.v1 - t.in0;
                 tile.xpar = (t.in0 + pad) & 1;                                   // (-1)^(image column + pad): the call's column 0 is image column in0
                 tile.plane_strips = strips_full;
+                tile.g = g;
                 tile.t0 = (b.v0 - b.in0 + tile.ypar) >> 1;                        // the pairs that hold a kept row
                 tile.tn = ((b.v1 - 1 - b.in0 + tile.ypar) >> 1) - tile.t0 + 1;
                 tile.band_step = nb > 1 ? step : 0;
                 tile.vr_max = vr_max;
                 if (nb == 1 && tile.vr1 > vr_max) tile.vr1 = vr_max;
                 TimedLaunch tl(ctx, 0, 1);
-                HIP_TRY(ctx, p.tl_row[ti]->row_u8(ctx->stream, inter + static_cast<size_t>(t.in0 / 8) * npairs * 16, dst, brows, t.in1 - t.in0, t.padmode, nb, ctx->num_cus,
+                HIP_TRY(ctx, p.tl_row[ti]->row_u8(ctx->stream, inter + static_cast<size_t>(t.in0 / g) * npairs * (2 * g), dst, brows, t.in1 - t.in0, t.padmode, nb, ctx->num_cus,
                                                   ctx->d_w256, p.tl_tw0_row[ti], p.tl_m_row[ti], tile));
             }
             bi += nb;
@@ -2230,7 +2231,9 @@ static int blur_u8c3_batch_impl(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_
             { TimedLaunch t(ctx, 1, nf);
               HIP_TRY(ctx, p.wr_col->col_u8(ctx->stream, s, ctx->work, rows, cols, p.sz.pad, nf, ctx->num_cus, ctx->d_w256, p.wr_tw0_col, p.wr_m_col, WrColTerm{})); }
             { TimedLaunch t(ctx, 0, nf);
-              HIP_TRY(ctx, p.wr_row->row_u8(ctx->stream, ctx->work, d, rows, cols, p.sz.pad, nf, ctx->num_cus, ctx->d_w256, p.wr_tw0_row, p.wr_m_row, WrRowTile{})); }
+              WrRowTile whole;
+              whole.g = p.wr_col->g;
+              HIP_TRY(ctx, p.wr_row->row_u8(ctx->stream, ctx->work, d, rows, cols, p.sz.pad, nf, ctx->num_cus, ctx->d_w256, p.wr_tw0_row, p.wr_m_row, whole)); }
             continue;
         }
         if (int rc = run_rowpass_u8c3(ctx, s, ctx->work, rows, cols, nf, p, p.tile_w)) return rc;

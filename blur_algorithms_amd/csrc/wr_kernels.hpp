@@ -320,7 +320,7 @@ template <int R0> __host__ __device__ constexpr size_t wr_tw0_bytes() { return s
 // LDS traffic interleave), and the middle of task t is the other.
 // rows of the LDS byte stage are one dword further apart than their 6C bytes: with 24-byte rows the 64 lanes of a pass-0
 // byte read (16 rows x 4 lines) pile three deep on the 32 banks; 7 dwords per row are coprime to the bank count
-template <int C> __host__ __device__ constexpr int wr_col_stage_row() { return 2 * C * 3 + 4; }
+template <int C> __host__ __device__ constexpr int wr_col_stage_row() { return C == 2 ? 12 : 2 * C * 3 + 4; }     // (C = 2: 3 dwords are odd already)
 template <int R0, int C> __host__ __device__ constexpr size_t wr_col_lds(int rows)
 {
     return static_cast<size_t>(C) * wr_col_line_stride<R0>() * sizeof(float2) + wr_tw0_bytes<R0>() + ((static_cast<size_t>(rows) + 1) * wr_col_stage_row<C>() + 15) / 16 * 16;
@@ -353,6 +353,7 @@ struct WrRowTile {
     int xpar = 0;                  // parity of (image column of the call's column 0 + the kernel's half width): sign of h's term
     int plane_strips = 0;          // strips of 8 columns per channel plane of the intermediate (0: the call's)
     int t0 = 0, tn = 0;            // row pairs [t0, t0 + tn) of a frame are transformed (tn = 0: all): the others hold no row that is written
+    int g = 8;                     // columns per strip of the intermediate (WrEntry::g of the column kernel that wrote it)
     int band_step = 0;             // > 0: the call's "frames" are bands of ONE image, band_step image rows apart (row_base, vr0, vr1 of band 0)
     int vr_max = 0;                // band_step > 0: no image row from vr_max on is written (the last band may reach into the next span's rows)
 };
@@ -369,9 +370,10 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
     constexpr int RS = wr_col_stage_row<C>();        // bytes between rows of the LDS byte stage
     constexpr int NSB = C * R0;                       // sub-blocks per task
     constexpr int LS = wr_col_line_stride<R0>();      // complex elements between lines
-    static_assert(C == 4, "lane numbering of pass 0: bit 0 = row parity, bits 1-2 = line, bits 3-5 = row pair");
+    static_assert(C == 4 || C == 2, "lane numbering of pass 0: bit 0 = row parity, bits 1 .. log2 C = line, the bits above = row pair");
     static_assert(NSB * 16 <= T && T % 64 == 0, "the middle section is one round");
-    static_assert(RB % 8 == 0, "a strip row is a whole number of 8-byte pieces");
+    static_assert(RB % 8 == 0 || RB == 12, "a strip row is a whole number of 8-byte pieces, or one 12-byte piece (C = 2)");
+    constexpr int LB = C == 4 ? 2 : 1;                // log2 C
     constexpr int total0 = C * kWrS, IT0 = (total0 + T - 1) / T;
     constexpr int N = R0 * kWrS;
     constexpr int NE = ELO + EHI > 0 ? ELO + EHI : 1;
@@ -391,11 +393,12 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
     wr_mid_load<R0>(wm, lane16, mid_on ? sbi % R0 : 0, w256, mult);
 
     // raw strip rows in registers, 8-byte pieces, requested a few at a time over the three tasks before they are needed
-    constexpr int PIECES = RB / 8;
+    constexpr int PB = RB % 8 == 0 ? 8 : 12, PD = PB / 4;      // bytes / dwords per piece
+    constexpr int PIECES = RB / PB;
     constexpr int KU = (PIECES * N + T - 1) / T;      // rows < N
     constexpr int KP = (KU + 2) / 3;                  // pieces per task
-    typedef unsigned int wr_u32x2 __attribute__((ext_vector_type(2)));
-    wr_u32x2 pfu[KU];
+    typedef unsigned int wr_piece __attribute__((ext_vector_type(PD)));
+    wr_piece pfu[KU];
     const size_t frame_bytes = static_cast<size_t>(term.band_step > 0 ? term.band_step : rows) * cols * CH;     // bands of one image overlap in memory
     const int npiece = rows * PIECES;
     auto strip_fast = [&](int uu) { const int ss = uu % nstrips; return aligned8 != 0 && (ss + 1) * G <= cols; };
@@ -412,16 +415,19 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
             idx = idx < npiece ? idx : npiece - 1;              // unconditional loads: all in flight together
             const int r = idx / PIECES, d = idx - r * PIECES;
 #ifdef WR_ABL_NOLOAD
-            pfu[k] = wr_u32x2{ static_cast<unsigned>(r), static_cast<unsigned>(d) };
+            pfu[k] = wr_piece(static_cast<unsigned>(r + d));
             (void)base;
 #else
-            pfu[k] = *reinterpret_cast<const wr_u32x2*>(base + static_cast<size_t>(r) * cols * CH + 8 * d);
+            pfu[k] = *reinterpret_cast<const wr_piece*>(base + static_cast<size_t>(r) * cols * CH + PB * d);
 #endif
         }
     };
     auto claim_strip = [&]() {
 #pragma unroll
-        for (int k = 0; k < KU; ++k) asm volatile("" ::"v"(pfu[k].x), "v"(pfu[k].y));
+        for (int k = 0; k < KU; ++k) {
+#pragma unroll
+            for (int d = 0; d < PD; ++d) asm volatile("" ::"v"(pfu[k][d]));
+        }
     };
     auto commit_strip = [&](int uu) {
         if (strip_fast(uu)) {
@@ -430,9 +436,9 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
                 const int idx = tid + T * k;
                 if (idx < npiece) {
                     const int r = idx / PIECES, d = idx - r * PIECES;
-                    unsigned* o = reinterpret_cast<unsigned*>(stage + r * RS + 8 * d);      // rows are 4-byte aligned only
-                    o[0] = pfu[k].x;
-                    o[1] = pfu[k].y;
+                    unsigned* o = reinterpret_cast<unsigned*>(stage + r * RS + PB * d);      // rows are 4-byte aligned only
+#pragma unroll
+                    for (int w = 0; w < PD; ++w) o[w] = pfu[k][w];
                 }
             }
         } else {
@@ -450,8 +456,9 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
     // Pass-0 butterfly g (0 .. C*256-1) -> (line l, butterfly j): inside a wave, lane bit 0 = j & 1 (the two rows of a
     // pair), bits 1-2 = l, bits 3-5 = (j >> 1) & 7.  The eight lanes of a row pair then hold the pair's whole 64-byte
     // record, and a wave's store covers eight consecutive records: 512 contiguous bytes.
-    auto line_of = [](int g) { return (g >> 1) & 3; };
-    auto bfly_of = [](int g) { return ((g >> 6) << 4) | (((g >> 3) & 7) << 1) | (g & 1); };
+    // (C = 2: bit 1 = l, bits 2-5 = (j >> 1) & 15: the four lanes of a row pair hold its 32-byte record, a wave's store covers sixteen)
+    auto line_of = [](int g) { return (g >> 1) & (C - 1); };
+    auto bfly_of = [](int g) { return ((g >> 6) << (6 - LB)) | (((g >> (1 + LB)) & ((1 << (5 - LB)) - 1)) << 1) | (g & 1); };
     // per-thread, per-round constants of the two pass-0 halves (loop invariant: a handful of registers)
     //   a_in[it]   byte address inside the stage of element (l, j - pad): interior rounds add k * 256 * RS as an immediate
     //   a_e[it][e] the same for the edge rounds (reflected row, or the zero row)
@@ -605,13 +612,15 @@ template <int R0> __host__ __device__ constexpr size_t wr_row_lds(int cols)
     return wr_lines_bytes<R0, 3>() + wr_tw0_bytes<R0>() + kWrTwlBytes + 2 * ((static_cast<size_t>(cols) * 3 + 15) / 16 * 16);
 }
 
-template <int R0, int T, int ELO, int EHI>
+// G: columns per strip of the intermediate the column kernel wrote (8: C = 4 lines per task; 4: the C = 2 kernels for long columns)
+template <int R0, int T, int ELO, int EHI, int G = 8>
 __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ inter, uint8_t* __restrict__ dst,
                                                    int rows, int cols, int pad, int npairs, int nstrips, int nunits, int aligned16,
                                                    const float2* __restrict__ w256, const float2* __restrict__ tw0g, const float* __restrict__ mult,
                                                    WrRowTile tile)
 {
-    constexpr int CH = 3, C = 3, G = 8;
+    constexpr int CH = 3, C = 3, LG = G == 8 ? 3 : 2;
+    static_assert(G == 8 || G == 4, "strips of 8 or 4 columns");
     constexpr int NSB = C * R0;
     constexpr int NE = ELO + EHI > 0 ? ELO + EHI : 1;
     static_assert(T == C * kWrS, "pass 0: one butterfly per thread");
@@ -642,15 +651,15 @@ __global__ __launch_bounds__(T) void wr_rowpass_u8(const float* __restrict__ int
     // per-thread constants (loop invariant, a handful of registers): byte offset of column j - pad inside a (channel, pair)
     // record set -- interior rounds add k * 32 strips -- and of the reflected columns of the edge rounds (~0u: zero)
     const int jm = j - pad;
-    const unsigned off_in = static_cast<unsigned>(((jm >> 3) * strip_step + 2 * (jm & 7)) * 4);
+    const unsigned off_in = static_cast<unsigned>(((jm >> LG) * strip_step + 2 * (jm & (G - 1))) * 4);
     unsigned off_e[NE];
 #pragma unroll
     for (int e = 0; e < ELO + EHI; ++e) {
         const int k = e < ELO ? e : R0 - EHI + (e - ELO);
         const int x = wr_reflect(j + k * kWrS, pad, cols);
-        off_e[e] = x < 0 ? ~0u : static_cast<unsigned>(((x >> 3) * strip_step + 2 * (x & 7)) * 4);
+        off_e[e] = x < 0 ? ~0u : static_cast<unsigned>(((x >> LG) * strip_step + 2 * (x & (G - 1))) * 4);
     }
-    const unsigned round_step = static_cast<unsigned>(32 * strip_step * 4);   // bytes between rounds: 256 columns = 32 strips
+    const unsigned round_step = static_cast<unsigned>((kWrS / G) * strip_step * 4);   // bytes between rounds: 256 columns = 32 (64) strips
     const int st_off = jm * CH + c;                              // stage byte of column j - pad, row slot 0; slot 1 at + stage_row
 
     typedef float wr_f32x2 __attribute__((ext_vector_type(2)));
@@ -875,6 +884,7 @@ __global__ __launch_bounds__(T) void wr_lines_kernel(const float2* __restrict__ 
 struct WrEntry {
     int r0;          // N = 256 * r0
     int threads;
+    int g;           // column role: columns per strip of the intermediate it writes (8, or 4 for the C = 2 kernels); row role: 0
     // columns first: u8 frames -> intermediate
     hipError_t (*col_u8)(hipStream_t, const uint8_t* src, float* inter, int rows, int cols, int pad, int nframes, int num_cus,
                          const float2* w256, const float2* tw0, const float* mult, WrColTerm term);
@@ -888,7 +898,7 @@ struct WrEntry {
 };
 
 inline int wr_npairs(int rows, int pad) { return ((rows - 1 + pad) >> 1) - (pad >> 1) + 1; }
-inline size_t wr_frame_floats(int rows, int cols, int pad) { return static_cast<size_t>((cols + 7) / 8) * wr_npairs(rows, pad) * 16 * 3; }
+inline size_t wr_frame_floats(int rows, int cols, int pad, int g = 8) { return static_cast<size_t>((cols + g - 1) / g) * wr_npairs(rows, pad) * (2 * g) * 3; }
 
 inline int wr_balanced_grid(int units, int slots)
 {
@@ -930,13 +940,15 @@ hipError_t wr_launch_row_u8(hipStream_t st, const float* inter, uint8_t* dst, in
     if (cols + 2 * pad > R0 * kWrS || pad > cols - 1) return hipErrorInvalidValue;
     const size_t lds = wr_row_lds<R0>(cols);
     const int elo = (pad + kWrS - 1) / kWrS, ehi = R0 - (pad + cols) / kWrS;
-    auto kern = (elo <= 1 && ehi <= 1) ? wr_rowpass_u8<R0, T, 1, 1> : wr_rowpass_u8<R0, T, R0, 0>;
+    auto kern = tile.g == 4 ? ((elo <= 1 && ehi <= 1) ? wr_rowpass_u8<R0, T, 1, 1, 4> : wr_rowpass_u8<R0, T, R0, 0, 4>)
+                            : ((elo <= 1 && ehi <= 1) ? wr_rowpass_u8<R0, T, 1, 1, 8> : wr_rowpass_u8<R0, T, R0, 0, 8>);
+    if (tile.g != 4 && tile.g != 8) return hipErrorInvalidValue;
     if (hipError_t e = wr_set_lds(kern, lds); e != hipSuccess) return e;
     // (a band of a tiled image: the rows pair up by the COLUMN call's padding, tile.ypar)
-    const int nstrips = (cols + 7) / 8, npairs = tile.ypar < 0 ? wr_npairs(rows, pad) : ((rows - 1 + tile.ypar) >> 1) + 1;
+    const int nstrips = (cols + tile.g - 1) / tile.g, npairs = tile.ypar < 0 ? wr_npairs(rows, pad) : ((rows - 1 + tile.ypar) >> 1) + 1;
     if (tile.tn > 0 && (tile.t0 < 0 || tile.t0 + tile.tn > npairs)) return hipErrorInvalidValue;
     const int nunits = (tile.tn > 0 ? tile.tn : npairs) * nframes;
-    if (static_cast<size_t>(tile.plane_strips > 0 ? tile.plane_strips : nstrips) * npairs * 16 >= (static_cast<size_t>(1) << 30)) return hipErrorInvalidValue;
+    if (static_cast<size_t>(tile.plane_strips > 0 ? tile.plane_strips : nstrips) * npairs * (2 * tile.g) >= (static_cast<size_t>(1) << 30)) return hipErrorInvalidValue;
     const int aligned16 = ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && ((static_cast<size_t>(cols) * 3) & 15) == 0) ? 1 : 0;
     const int grid = wr_balanced_grid(nunits, num_cus);
     hipLaunchKernelGGL(kern, dim3(grid), dim3(T), lds, st, inter, dst, rows, cols, pad, npairs, nstrips, nunits, aligned16, w256, tw0, mult, tile);
@@ -964,7 +976,7 @@ hipError_t wr_launch_lines(hipStream_t st, const float2* in, float2* out, int nl
     namespace blur_amd {                                                                          \
     const WrEntry* wr_col_entry_##R0_()                                                           \
     {                                                                                             \
-        static const WrEntry e = { R0_, T_, wr_launch_col_u8<R0_, C_, T_>, wr_col_lds<R0_, C_>, nullptr, nullptr, \
+        static const WrEntry e = { R0_, T_, 2 * C_, wr_launch_col_u8<R0_, C_, T_>, wr_col_lds<R0_, C_>, nullptr, nullptr, \
                                    wr_launch_lines<R0_, C_, T_> };                                \
         return &e;                                                                                \
     }                                                                                             \
@@ -973,7 +985,7 @@ hipError_t wr_launch_lines(hipStream_t st, const float2* in, float2* out, int nl
     namespace blur_amd {                                                                          \
     const WrEntry* wr_row_entry_##R0_()                                                           \
     {                                                                                             \
-        static const WrEntry e = { R0_, T_, nullptr, nullptr, wr_launch_row_u8<R0_, T_>, wr_row_lds<R0_>, \
+        static const WrEntry e = { R0_, T_, 0, nullptr, nullptr, wr_launch_row_u8<R0_, T_>, wr_row_lds<R0_>, \
                                    wr_launch_lines<R0_, 3, T_> };                                 \
         return &e;                                                                                \
     }                                                                                             \

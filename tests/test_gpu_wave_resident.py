@@ -147,7 +147,8 @@ def test_wave_resident_is_the_fft_choice_on_the_metric_frame(ctx):
     assert (m != d).float().mean().item() < 1e-4
 
 
-@pytest.mark.parametrize("role,r0", [("col", r) for r in (3, 4, 5, 6, 8, 9, 10)] + [("row", r) for r in (3, 4, 5, 6, 8, 9, 10, 12, 15, 16)])
+# (column role R0 = 12, 15, 16: the C = 2 kernels of round 4, strips of 4 columns)
+@pytest.mark.parametrize("role,r0", [("col", r) for r in (3, 4, 5, 6, 8, 9, 10, 12, 15, 16)] + [("row", r) for r in (3, 4, 5, 6, 8, 9, 10, 12, 15, 16)])
 @pytest.mark.parametrize("sigma", [3.0, 20.0])
 def test_every_registered_length_in_its_role(ctx, role, r0, sigma):
     """a thin image whose long side lands on N = 256 * R0 in the column or the row role (the other side takes the smallest
@@ -178,4 +179,18 @@ def test_config2_frame_1080p_wave_resident(ctx):
     want, planes = O.pffft_blur_u8c3_f64(img, 20.0, True, want_planes=True)
     t = torch.from_numpy(img).cuda()
     got = ctx.pffft_(t, 20.0, out=torch.empty_like(t), wave_resident=True)
+    assert_u8_parity(got.cpu().numpy(), want, planes)
+
+
+@pytest.mark.parametrize("rows,cols,sigma", [(3300, 2200, 57.0), (3705, 1000, 30.0), (2900, 517, 44.0), (3600, 1283, 20.0)])
+def test_long_columns_whole_image(ctx, rows, cols, sigma):
+    """columns of 2561 .. 4096 padded points: the C = 2 column kernels (strips of 4 columns) and a row kernel reading 4-column strips,
+    the whole image in one transform per line; ragged widths, quirk on"""
+    torch = _torch()
+    from oracle import oracle as O
+    img = _rand_img(rows, cols, rows + cols)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, True, want_planes=True)
+    t = torch.from_numpy(img).cuda()
+    got = ctx.pffft_(t, sigma, out=torch.empty_like(t), wave_resident=True)
+    assert ctx.last_family() == 2
     assert_u8_parity(got.cpu().numpy(), want, planes)

@@ -1,7 +1,7 @@
 #!/bin/bash
 cd /tmp && export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/s7; rm -rf $O; mkdir -p $O
-for sh in "2625 1750 51.23" "4425 2950 66.52" "11400 7600 106.77"; do
+for sh in "1500 1000 38.73" "2400 1600 48.99" "4425 2950 66.52"; do
   set -- $sh
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/k_$1 -- python3 $GRAFT_REPO_ROOT/tools/one_shape.py $1 $2 $3 1 > $O/k_$1.log 2>&1
   tail -1 $O/k_$1.log
@@ -13,7 +13,7 @@ PY
   t=$(find $O/k_$1 -name "*kernel_trace.csv" | head -1); python3 - "$t" <<'PY'
 import csv,sys
 rows=list(csv.DictReader(open(sys.argv[1])))
-rows=[r for r in rows if "wr_" in r["Kernel_Name"] or "fx_prepass" in r["Kernel_Name"] or "tl_terms" in r["Kernel_Name"]]
+rows=[r for r in rows if "blur_amd" in r["Kernel_Name"] or "anonymous" in r["Kernel_Name"] and "at::native" not in r["Kernel_Name"]]
 n=len(rows)//7
 last=rows[-n:]
 t0=int(last[0]["Start_Timestamp"])
