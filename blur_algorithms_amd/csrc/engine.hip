@@ -2316,6 +2316,8 @@ int blur_rowpass_u8c3_dev(blur_ctx* ctx, const uint8_t* d_src, float* d_planes, 
         // the fused kernel's row-pass planes (tests): the whole blur runs, its bytes go to the workspace and are dropped
         const bool aligned = (reinterpret_cast<uintptr_t>(d_src) & 3) == 0;
         if (int rc = prepare(ctx, rows, cols, sigma, opts, p, true, nullptr, true, aligned)) return rc;
+        if (!p.fx || p.fx->nkb > 11 || (cols & 3) != 0)
+            return fail(ctx, BLUR_ERR_UNSUPPORTED, "row-pass planes of the fused engine: a test instantiation for pad <= 72 and widths that are multiples of 4");
         const size_t bytes = static_cast<size_t>(rows) * cols * 3;
         if (int rc = ensure_work(ctx, 2 * bytes + 64)) return rc;
         return run_fx_u8c3(ctx, d_src, reinterpret_cast<uint8_t*>(ctx->work) + ((bytes + 63) & ~static_cast<size_t>(63)), 1, rows, cols, p, d_planes);
