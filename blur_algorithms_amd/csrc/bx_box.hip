@@ -135,7 +135,12 @@ __global__ __launch_bounds__(256) void bx_vert_kernel(const uint8_t* __restrict_
 #pragma unroll
             for (int d = 0; d < W; ++d) win[a][t][d] = 0;
 
-    u4 ld[2][NT / 4];
+#ifndef BX_VPF
+#define BX_VPF 2
+#endif
+    constexpr int VPF = BX_VPF;              // steps of loads in flight
+    static_assert((2 * W) % VPF == 0, "the prefetch ring is indexed statically");
+    u4 ld[VPF][NT / 4];
     auto issue = [&](int s, u4 (&dst)[NT / 4]) __attribute__((always_inline)) {
         int row = R0 + 16 * s + 4 * q + p;
         row = row < 0 ? -row : row;
@@ -144,15 +149,16 @@ __global__ __launch_bounds__(256) void bx_vert_kernel(const uint8_t* __restrict_
 #pragma unroll
         for (int k = 0; k < NT / 4; ++k) dst[k] = __builtin_amdgcn_raw_buffer_load_b128(rin, off + 16 * k, 0, 0);
     };
-    issue(0, ld[0]);
-    if (S > 1) issue(1, ld[1]);
+#pragma unroll
+    for (int k = 0; k < VPF; ++k)
+        if (k < S) issue(k, ld[k]);
 
     for (int s0 = 0; s0 < S; s0 += 2 * W) {
 #pragma unroll
         for (int uu = 0; uu < 2 * W; ++uu) {
             const int s = s0 + uu, slot = uu % W;
             if (s >= S) break;
-            u4 (&cur)[NT / 4] = ld[uu & 1];
+            u4 (&cur)[NT / 4] = ld[uu % VPF];
             uint32_t res[NT];
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(256) void bx_vert_kernel(const uint8_t* __restrict_
                     if (a + 1 < P) win[a + 1][t][slot] = pk; else res[t] = pk;
                 }
             }
-            if (s + 2 < S) issue(s + 2, cur);
+            if (s + VPF < S) issue(s + VPF, cur);
             if (s >= FILL) {
                 const int row = ys + 16 * (s - FILL) + 4 * q + p;
                 const bool rok = row < ye;
@@ -441,6 +447,212 @@ hipError_t bx_launch_horz_p(hipStream_t st, const uint8_t* in, uint8_t* out, uin
     }
 }
 
+// ---- horizontal, three channels, by channel plane ------------------------------------------------------------------------
+// Over interleaved RGB the band above has its taps on every third byte: two thirds of every matrix instruction multiply zeros,
+// and a box of 41 taps needs a window of three instructions (reach 60 bytes) where 20 PIXELS of reach fit one.  Here a step is 16
+// pixels (48 bytes of a row): lane (n = row, q) loads the 12 bytes of pixels 4 q .. 4 q + 3 itself (a wave's load = 16 rows x 48
+// contiguous bytes; no transposes across the lane groups), six v_perm_b32 split them into the three channels' window dwords --
+// exactly the layout of the vertical kernel with the channels in the place of its column tiles -- and six more put the three
+// result dwords back together as 12 bytes.  The few steps that reach over an end of the row gather their mirrored pixels one by one.  Per 16 pixels and sweep: 3 NB instructions instead of 3 NB' with NB' = ceil((3 r +
+// 8) / 32) >= 2 NB.  Any width and any alignment (12-byte loads and stores at byte addresses work on gfx950:
+// tools/probes/unaligned_probe.hip); a quad of pixels cut by the end of the row leaves byte by byte.
+template <int NB, int P>
+__global__ __launch_bounds__(256) void bx_horz3_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, BxHorzGeom g, int s_band, uint32_t mul, int nwaves)
+{
+#ifndef BX_PF
+#define BX_PF 4
+#endif
+    constexpr int W = 4 * NB, DELTA = 32 * NB - 8, FILL = P * (W - 1), PF = BX_PF;      // PF: steps of loads in flight
+    static_assert((2 * W) % PF == 0, "the prefetch ring is indexed statically");
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * 4 + (threadIdx.x >> 6)));      // wave-uniform: scalar branches below
+    if (wid >= nwaves) return;
+    const int l = threadIdx.x & 63, n = l & 15, q = l >> 4;
+    const int grp = wid % g.ngroups, seg = wid / g.ngroups;
+    const int w = g.pitch / 3, seg_px = g.seg_bytes / 3;
+    const int xs = seg * seg_px, xe = min(w, xs + seg_px);
+    const int S = FILL + (xe - xs + 15) / 16;
+    // sweep a's tile of step s covers pixels X0 - a DELTA + 16 s ..; the last sweep's tile of step FILL starts at xs
+    const int X0 = xs + P * DELTA - 16 * FILL;
+    const uint32_t obytes = static_cast<uint32_t>(g.h) * static_cast<uint32_t>(g.pitch);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc(out, 0, obytes, kRsrcWord3);
+
+    v4i band[W];
+#pragma unroll
+    for (int u = 0; u < W; ++u) band[u] = bx_band<NB>(u, n, q, g.r, 1, s_band);
+    const int nt = 2 * g.r + 1, bias_last = s_band * (128 * nt + g.r), bias_mid = s_band * (256 * nt + g.r);
+    const v4i cin_last = { bias_last, bias_last, bias_last, bias_last }, cin_mid = { bias_mid, bias_mid, bias_mid, bias_mid };
+
+    const int row = grp * 16 + n;
+    const bool rok = row < g.h;
+    const int rc = rok ? row : g.h - 1;
+    const uint8_t* irow = in + static_cast<size_t>(rc) * g.pitch;
+    const uint32_t orow = static_cast<uint32_t>(rc) * static_cast<uint32_t>(g.pitch);
+
+    uint32_t win[P][3][W];
+#pragma unroll
+    for (int a = 0; a < P; ++a)
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int d = 0; d < W; ++d) win[a][c][d] = 0;
+
+    // a step that lies inside the row (wave-uniform test) is one buffer load / store with the step in the scalar offset: no vector
+    // arithmetic per step; steps that touch a margin or the cut end of the row pick their addresses per lane
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(in), 0, obytes, kRsrcWord3);
+    const uint32_t vin = orow + 12u * q, vout = rok ? orow + 12u * q : kDropped;
+    u3 ld[PF];
+    auto issue = [&](int s, u3& dst) __attribute__((always_inline)) {
+        const int p0 = 3 * (X0 + 16 * s);                            // byte of the row where the step starts (wave-uniform)
+        if (p0 >= 0 && p0 + 48 <= g.pitch) {
+            dst = __builtin_amdgcn_raw_buffer_load_b96(rin, vin, p0, 0);
+        } else {
+            // a step that reaches over an end of the row (a few per row, in the first and last segment).  A quad of pixels that lies
+            // wholly beyond an end is the pixel-reversed copy of four adjacent pixels of the row: one 12-byte load and the reversal;
+            // quads cut by the end (widths that are no multiple of 4) or mirrored more than once (tiny rows) go pixel by pixel
+            const int X = X0 + 16 * s + 4 * q;
+            const bool lo = X + 3 < 0, hi = X >= w, mir = lo || hi;
+            const int xq = lo ? -X - 3 : (hi ? 2 * (w - 1) - X - 3 : X);
+            const bool simple = xq >= 0 && xq + 3 < w;
+            if (!__any(!simple)) {
+                const u3 t = *reinterpret_cast<const u3*>(irow + 3 * xq);
+                // pixels 3, 2, 1, 0 of the loaded four: bytes [9 10 11 6] [7 8 3 4] [5 0 1 2]
+                const uint32_t r0 = __builtin_amdgcn_perm(t[2], t[1], 0x02070605u);
+                const uint32_t r1 = (t[1] >> 24) | ((t[2] & 0xffu) << 8) | ((t[0] >> 24) << 16) | ((t[1] & 0xffu) << 24);
+                const uint32_t r2 = __builtin_amdgcn_perm(t[1], t[0], 0x02010005u);
+                dst[0] = mir ? r0 : t[0]; dst[1] = mir ? r1 : t[1]; dst[2] = mir ? r2 : t[2];
+            } else {
+                uint32_t b[12];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    int x = X + k;
+                    for (int it = 0; it < 64 && (x < 0 || x >= w); ++it) {
+                        x = x < 0 ? -x : x;
+                        x = x >= w ? 2 * (w - 1) - x : x;
+                    }
+                    const uint8_t* px = irow + 3 * x;
+                    b[3 * k] = px[0]; b[3 * k + 1] = px[1]; b[3 * k + 2] = px[2];
+                }
+                dst[0] = b[0] | (b[1] << 8) | (b[2] << 16) | (b[3] << 24);
+                dst[1] = b[4] | (b[5] << 8) | (b[6] << 16) | (b[7] << 24);
+                dst[2] = b[8] | (b[9] << 8) | (b[10] << 16) | (b[11] << 24);
+            }
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < PF; ++k)
+        if (k < S) issue(k, ld[k]);
+
+    for (int s0 = 0; s0 < S; s0 += 2 * W) {
+#pragma unroll
+        for (int uu = 0; uu < 2 * W; ++uu) {
+            const int s = s0 + uu, slot = uu % W;
+            if (s >= S) break;
+            const u3 cur = ld[uu % PF];
+            if (s + PF < S) issue(s + PF, ld[uu % PF]);
+            // pixels p = 0 .. 3, channel c = byte 3 p + c of the 12: -> one dword per channel (signed: x ^ 0x80)
+            const uint32_t d0 = cur[0] ^ 0x80808080u, d1 = cur[1] ^ 0x80808080u, d2 = cur[2] ^ 0x80808080u;
+            uint32_t ch[3];
+            ch[0] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00060300u), 0x05020100u);      // bytes 0, 3, 6, 9
+            ch[1] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00070401u), 0x06020100u);      // bytes 1, 4, 7, 10
+            ch[2] = __builtin_amdgcn_perm(d2, __builtin_amdgcn_perm(d1, d0, 0x00000502u), 0x07040100u);      // bytes 2, 5, 8, 11
+            uint32_t res[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) win[0][c][slot] = ch[c];
+#pragma unroll
+            for (int a = 0; a < P; ++a) {
+                // the three channels' products are independent of each other: issued together, packed together (one pair of waits)
+                v4i d[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    d[c] = a + 1 < P ? cin_mid : cin_last;
+#pragma unroll
+                    for (int G = 0; G < NB; ++G) {
+                        const v4i bop = { static_cast<int>(win[a][c][4 * G]), static_cast<int>(win[a][c][4 * G + 1]), static_cast<int>(win[a][c][4 * G + 2]),
+                                          static_cast<int>(win[a][c][4 * G + 3]) };
+                        d[c] = __builtin_amdgcn_mfma_i32_16x16x64_i8(band[(slot - 4 * G + W) % W], bop, d[c], 0, 0, 0);
+                    }
+                }
+                // (the SDWA form of the multiply -- 4 instructions per dword instead of 7, its waits carried inside the inline assembly --
+                // gave equal bytes and equal time here, 52.2 against 52.7 us at 8K: the kernel waits on memory, so the plain form stays)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const uint32_t pk = bx_pack(d[c], mul);
+                    if (a + 1 < P) win[a + 1][c][slot] = pk; else res[c] = pk;
+                }
+            }
+            if (s >= FILL) {
+                const int px = xs + 16 * (s - FILL) + 4 * q;
+                // res[c] = channel c of pixels px .. px + 3 -> 12 interleaved bytes
+                const uint32_t X = __builtin_amdgcn_perm(res[1], res[0], 0x05010400u);      // [r0.0, r1.0, r0.1, r1.1]
+                const uint32_t Y = __builtin_amdgcn_perm(res[1], res[0], 0x07030602u);      // [r0.2, r1.2, r0.3, r1.3]
+                const uint32_t w0 = __builtin_amdgcn_perm(res[2], X, 0x02040100u);          // [X0, X1, r2.0, X2]
+                const uint32_t Z = __builtin_amdgcn_perm(res[2], X, 0x0c0c0503u);           // [X3, r2.1, 0, 0]
+                const uint32_t w1 = __builtin_amdgcn_perm(Y, Z, 0x05040100u);               // [Z0, Z1, Y0, Y1]
+                const uint32_t w2 = __builtin_amdgcn_perm(res[2], Y, 0x07030206u);          // [r2.2, Y2, Y3, r2.3]
+                const uint32_t off = orow + 3u * static_cast<uint32_t>(px);
+                const u3 wv = { w0, w1, w2 };
+                const int p0 = xs + 16 * (s - FILL);                    // (wave-uniform)
+                if (p0 + 16 <= xe) {
+                    __builtin_amdgcn_raw_buffer_store_b96(wv, rout, vout, 3 * p0, 0);
+                } else {                                                // the row's last, cut step: a cut quad leaves as single bytes
+                    __builtin_amdgcn_raw_buffer_store_b96(wv, rout, (rok && px + 4 <= xe) ? off : kDropped, 0, 0);
+                    const int tail = (rok && px < xe && px + 4 > xe) ? 3 * (xe - px) : 0;
+#pragma unroll
+                    for (int b = 0; b < 9; ++b) {
+                        const uint32_t word = b < 4 ? w0 : (b < 8 ? w1 : w2);
+                        __builtin_amdgcn_raw_buffer_store_b8(static_cast<uint8_t>(word >> (8 * (b & 3))), rout, b < tail ? off + b : kDropped, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+template <int NB, int P>
+hipError_t bx_launch_horz3(hipStream_t st, const uint8_t* in, uint8_t* out, BxHorzGeom g, int s_band, uint32_t mul, int num_cus)
+{
+    constexpr int FILL = P * (4 * NB - 1);
+    const int w = g.pitch / 3;
+    g.ngroups = (g.h + 15) / 16;
+    // segments of a row: waves for every SIMD, none shorter than twice the pixels it takes to fill its pipeline
+    // (8K, k = 41, P = 3, 270 row groups: 63 / 49 / 55 / 49 / 55 / 51 / 56 us with 6 / 7 / 9 / 11 / 13 / 15 / 22 segments: the waves should come to
+    // just under a whole number per SIMD -- 2 (7 segments) and 3 (11) do, 2.4 (9) and 3.4 (13) leave SIMDs waiting for the others)
+    int nseg = (bx_env("BLUR_BX_HWAVES") > 0 ? bx_env("BLUR_BX_HWAVES") : 12) * num_cus / g.ngroups;
+    const int most = w / (2 * 16 * FILL);
+    if (nseg > most) nseg = most;
+    if (bx_env("BLUR_BX_HSEG") > 0) nseg = bx_env("BLUR_BX_HSEG");
+    if (nseg < 1) nseg = 1;
+    const int seg_px = ((w + nseg - 1) / nseg + 15) / 16 * 16;
+    g.seg_bytes = 3 * seg_px;
+    g.nseg = (w + seg_px - 1) / seg_px;
+    const int nwaves = g.ngroups * g.nseg;
+    hipLaunchKernelGGL((bx_horz3_kernel<NB, P>), dim3((nwaves + 3) / 4), dim3(256), 0, st, in, out, g, s_band, mul, nwaves);
+    return hipGetLastError();
+}
+
+template <int NB>
+hipError_t bx_launch_horz3_p(hipStream_t st, const uint8_t* in, uint8_t* out, BxHorzGeom g, int passes, int s_band, uint32_t mul, int num_cus)
+{
+    switch (passes) {
+    case 1: return bx_launch_horz3<NB, 1>(st, in, out, g, s_band, mul, num_cus);
+    case 2: return bx_launch_horz3<NB, 2>(st, in, out, g, s_band, mul, num_cus);
+    default: return bx_launch_horz3<NB, 3>(st, in, out, g, s_band, mul, num_cus);
+    }
+}
+
+// geometry of the channel-plane kernel: three channels, r <= 56, rows of at least 128 bytes
+bool bx_horz3_geom(int h, int w, int C, int r, int passes, BxHorzGeom* g)
+{
+    if (C != 3 || r < 1 || r > 56 || passes < 1 || passes > 3 || bx_env("BLUR_BX_NO_HORZ3")) return false;
+    const long long pitch = 3ll * w;
+    if (pitch < 128 || pitch * h >= (1ll << 31)) return false;
+    g->h = h; g->pitch = static_cast<int>(pitch); g->C = 3; g->r = r;
+    g->ml = g->mr = g->mpitch = 0;                      // (no margins: the kernel mirrors the row's ends itself)
+    g->seg_bytes = g->nseg = g->ngroups = 0;
+    return true;
+}
+
 // window blocks of 64 bytes for a reach of C r bytes; 0: wider than the instantiated kernels
 int bx_horz_blocks(int C, int r)
 {
@@ -487,6 +699,7 @@ hipError_t bx_vertical(hipStream_t st, const uint8_t* in, uint8_t* out, int h, i
 size_t bx_horizontal_scratch(int h, int w, int C, int r, int passes)
 {
     BxHorzGeom g;
+    if (bx_horz3_geom(h, w, C, r, passes, &g)) return 64;          // (the channel-plane kernel needs none)
     if (!bx_horz_geom(h, w, C, r, passes, &g)) return 0;
     return static_cast<size_t>(h) * g.mpitch + 64;
 }
@@ -497,6 +710,10 @@ hipError_t bx_horizontal(hipStream_t st, const uint8_t* in, uint8_t* out, uint8_
     int s_band = 0;
     uint32_t mul = 0;
     BxHorzGeom g;
+    if (bx_constants(r, &s_band, &mul) && bx_horz3_geom(h, w, C, r, passes, &g)) {
+        *ran = true;
+        return r <= 24 ? bx_launch_horz3_p<1>(st, in, out, g, passes, s_band, mul, num_cus) : bx_launch_horz3_p<2>(st, in, out, g, passes, s_band, mul, num_cus);
+    }
     if (!margins || !bx_constants(r, &s_band, &mul) || !bx_horz_geom(h, w, C, r, passes, &g)) return hipSuccess;
     if ((reinterpret_cast<uintptr_t>(in) & 3) || (reinterpret_cast<uintptr_t>(out) & 3) || (reinterpret_cast<uintptr_t>(margins) & 3)) return hipSuccess;
     *ran = true;

@@ -94,6 +94,25 @@ template <int CTRL> __device__ __forceinline__ uint32_t fx_dpp(uint32_t x)
     return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), CTRL, 0xf, 0xf, true));
 }
 
+#ifdef FX_ABL_M16
+// timing-only ablation: every 32x32x16 product replaced by two 16x16x32 products on quarter tiles (the same matrix-pipe cycles and
+// operand reads; the results are garbage) -- does the clock the chip grants depend on the shape?
+typedef float fx_f4 __attribute__((ext_vector_type(4)));
+struct fx_tile { fx_f4 q[4]; };
+#define FX_EL(t, i) ((t).q[(i) >> 2][(i) & 3])
+#define FX_PIN(t) asm volatile("" : "+a"((t).q[0]), "+a"((t).q[1]), "+a"((t).q[2]), "+a"((t).q[3]))
+__device__ __forceinline__ void fx_mma(mx_half8 a, mx_half8 b, fx_tile& t, int pair)
+{
+    t.q[2 * pair] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, t.q[2 * pair], 0, 0, 0);
+    t.q[2 * pair + 1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, t.q[2 * pair + 1], 0, 0, 0);
+}
+#else
+typedef mx_float16 fx_tile;
+#define FX_EL(t, i) ((t)[i])
+#define FX_PIN(t) asm volatile("" : "+a"(t))
+__device__ __forceinline__ void fx_mma(mx_half8 a, mx_half8 b, fx_tile& t, int) { t = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, t, 0, 0, 0); }
+#endif
+
 // 4 x 4 byte transpose inside a lane quad: lane j holds bytes M[j][0..3]; afterwards lane k holds M[0..3][k]
 __device__ __forceinline__ uint32_t fx_quad_transpose(uint32_t p, uint32_t sel1, uint32_t sel2)
 {
@@ -272,13 +291,18 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     const int qrows = 32 * (g.ntiles + NT);
     const double qrs = QUIRK ? static_cast<double>(qk.dr) * ((g.pad & 1) ? -1.0 : 1.0) : 0.0;
 
-    const mx_float16 zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
-    mx_float16 acc[3][NT];
+#ifdef FX_ABL_M16
+    const fx_f4 zero4 = { 0.f, 0.f, 0.f, 0.f };
+    const fx_tile zero = { { zero4, zero4, zero4, zero4 } };
+#else
+    const fx_tile zero = { 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f };
+#endif
+    fx_tile acc[3][NT];
 #pragma unroll
     for (int c = 0; c < 3; ++c)
 #pragma unroll
         for (int k = 0; k < NT; ++k) acc[c][k] = zero;
-    mx_float16 arow = zero;             // the row pass's accumulator
+    fx_tile arow = zero;             // the row pass's accumulator
     uint32_t hl[2][8];                  // hand-off: [hi, lo][packed row pairs], block b = entries 4 b .. 4 b + 3
     uint32_t rr[3][4];                  // finished tile, per channel and row group: 4 pixels of one row (after the quad transpose)
 
@@ -381,7 +405,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     // scheduling fence after every block keeps the slices where they are (a window read is in flight for three blocks)
     auto rowpass = [&](int buf, int c, auto beside) __attribute__((always_inline)) {
         const _Float16* base = reinterpret_cast<const _Float16*>(fx_lds + buf * C::BUF) + (c * 32 + m) * PW + wave * 32 + 8 * h;
-        mx_float16 a = zero;
+        fx_tile a = zero;
         mx_half8 x[4];
 #pragma unroll
 #ifdef FX_ABL_NOXREAD
@@ -394,9 +418,9 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #ifndef FX_ABL_NOXREAD
             if (kb + 3 < NKB) x[(kb + 3) & 3] = *reinterpret_cast<const mx_half8*>(base + 16 * (kb + 3));
 #endif
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[kb & 3], th[kb], a, 0, 0, 0);
-            a = __builtin_amdgcn_mfma_f32_32x32x16_f16(x[kb & 3], tl[kb], a, 0, 0, 0);
-            asm volatile("" : "+a"(a));          // pins the two products between this block's fences (they have no other side effect)
+            fx_mma(x[kb & 3], th[kb], a, 0);
+            fx_mma(x[kb & 3], tl[kb], a, 1);
+            FX_PIN(a);                           // pins the two products between this block's fences (they have no other side effect)
             beside(kb);
 #ifdef FX_SGB
             // inside the block: the slice's vector work after each product, not behind both
@@ -423,7 +447,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #ifdef FX_ABL_NOSPLIT
         if (sub == 0) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) { hp[4 * hf + k] = __builtin_bit_cast(uint32_t, arow[8 * hf + k]); lp[4 * hf + k] = __builtin_bit_cast(uint32_t, arow[8 * hf + 4 + k]); }
+            for (int k = 0; k < 4; ++k) { hp[4 * hf + k] = __builtin_bit_cast(uint32_t, FX_EL(arow, 8 * hf + k)); lp[4 * hf + k] = __builtin_bit_cast(uint32_t, FX_EL(arow, 8 * hf + 4 + k)); }
         }
         return;
 #endif
@@ -433,14 +457,14 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #pragma unroll
                 for (int k = 0; k < 2; ++k) {
                     const float4 t4 = *reinterpret_cast<const float4*>(qs4 + 8 * (2 * hf + k));
-                    sv[8 * hf + 4 * k] = __builtin_fmaf(arow[8 * hf + 4 * k], kFxRowUnscale, t4.x);
-                    sv[8 * hf + 4 * k + 1] = __builtin_fmaf(arow[8 * hf + 4 * k + 1], kFxRowUnscale, t4.y);
-                    sv[8 * hf + 4 * k + 2] = __builtin_fmaf(arow[8 * hf + 4 * k + 2], kFxRowUnscale, t4.z);
-                    sv[8 * hf + 4 * k + 3] = __builtin_fmaf(arow[8 * hf + 4 * k + 3], kFxRowUnscale, t4.w);
+                    sv[8 * hf + 4 * k] = __builtin_fmaf(FX_EL(arow, 8 * hf + 4 * k), kFxRowUnscale, t4.x);
+                    sv[8 * hf + 4 * k + 1] = __builtin_fmaf(FX_EL(arow, 8 * hf + 4 * k + 1), kFxRowUnscale, t4.y);
+                    sv[8 * hf + 4 * k + 2] = __builtin_fmaf(FX_EL(arow, 8 * hf + 4 * k + 2), kFxRowUnscale, t4.z);
+                    sv[8 * hf + 4 * k + 3] = __builtin_fmaf(FX_EL(arow, 8 * hf + 4 * k + 3), kFxRowUnscale, t4.w);
                 }
             } else {
 #pragma unroll
-                for (int k = 0; k < 8; ++k) sv[8 * hf + k] = arow[8 * hf + k] * kFxRowUnscale;
+                for (int k = 0; k < 8; ++k) sv[8 * hf + k] = FX_EL(arow, 8 * hf + k) * kFxRowUnscale;
             }
             if (DUMPV) {
                 const int x = x0 + 32 * wave + m;
@@ -470,17 +494,17 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
         }
     };
     // E: one row group (4 rows) of the finished tile -> bytes, 4 x 4 transposed inside the lane quads -> rr[c][gq]
-    mx_float16 tfin = zero;
+    fx_tile tfin = zero;
     auto emit_piece = [&](int c, int gq) __attribute__((always_inline)) {
 #ifdef FX_ABL_NOEMIT
-        rr[c][gq] = __builtin_bit_cast(uint32_t, tfin[5 * gq]);
+        rr[c][gq] = __builtin_bit_cast(uint32_t, FX_EL(tfin, 5 * gq));
         return;
 #endif
         float fv[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const int reg = 4 * gq + k;
-            fv[k] = __builtin_fmaf(tfin[reg], kMxUnscale, (reg & 1) ? cneg[c] : cpos[c]);
+            fv[k] = __builtin_fmaf(FX_EL(tfin, reg), kMxUnscale, (reg & 1) ? cneg[c] : cpos[c]);
         }
         // (uint8_t)(v + 0.5f) of the reference (Utils.hpp:189,204-206): truncate, keep the low byte (values past 255.5, which only
         // the quirk's terms reach, wrap as on x86) -- the conversion writes its byte of the packed dword itself (SDWA)
@@ -508,11 +532,11 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
         for (int it = 0; it < NKB; ++it) {
             const int d = it == 0 ? NKB - 1 : (it >= NKB - 2 ? it - (NKB - 2) : it + 1);
             const int b = d & 1, a2 = d >> 1, slot = (qs - a2 + 2 * NT) % NT;
-            mx_float16 t = d == 0 ? zero : acc[c][slot];
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v1[b], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(tl[d], v1[b], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v2[b], t, 0, 0, 0);
-            asm volatile("" : "+a"(t));          // pins the three products between this triple's fences
+            fx_tile t = d == 0 ? zero : acc[c][slot];
+            fx_mma(th[d], v1[b], t, 0);
+            fx_mma(tl[d], v1[b], t, 1);
+            fx_mma(th[d], v2[b], t, 0);
+            FX_PIN(t);                           // pins the three products between this triple's fences
             if (it == 0) tfin = t; else acc[c][slot] = t;
             beside(it);
 #ifdef FX_SGB
