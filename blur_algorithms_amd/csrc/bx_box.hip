@@ -109,6 +109,9 @@ __global__ __launch_bounds__(256) void bx_vert_kernel(const uint8_t* __restrict_
     const int wid = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.x * 4 + (threadIdx.x >> 6)));      // wave-uniform: scalar branches below
     if (wid >= nwaves) return;
     const int l = threadIdx.x & 63, n = l & 15, q = l >> 4, qd = n >> 2, p = n & 3;
+    // (Walking every other segment of a strip upwards, so that two neighbours read the P DELTA rows either side of their boundary at
+    // the same time, with or without the four segments of a strip in one workgroup, was measured at 8K: 53.5 and 69 us against 52 --
+    // the re-read rows do not cost memory bandwidth, and four adjacent strips per workgroup, 256 contiguous bytes of a row, matter.)
     const int strip = wid % nstrips, seg = wid / nstrips;
     const int ys = seg * seg_rows, ye = min(h, ys + seg_rows);
     const int S = FILL + (ye - ys + 15) / 16, R0 = ys - P * DELTA;

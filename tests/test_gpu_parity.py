@@ -409,10 +409,13 @@ def test_fastboxblur(ctx, w, h, ch, ksize, passes):
 # shapes that run on the integer matrix cores (csrc/bx_box.hip): every window size of the horizontal kernel (reach C r <= 24, 56,
 # 88, 120 bytes) and of the vertical one (r <= 24, 56), 1 / 3 / 4 channels, more than three passes (two launches per direction),
 # row pitches that are not a multiple of 16 bytes, heights that are not a multiple of 16, and shapes where one direction falls back
-# to the accumulator kernels (box wider than the windows, too few rows for the pipeline, pitch not a multiple of 4)
+# to the accumulator kernels (box wider than the windows, too few rows for the pipeline, pitch not a multiple of 4); round 4: three
+# channels run on the channel-plane kernel (r <= 24 and r <= 56; any width: rows that end in a cut quad of pixels, several segments
+# per row, rows shorter than the kernel's reach past their ends)
 BX_SHAPES = [(640, 480, 3, 41, 3), (256, 300, 1, 9, 2), (128, 200, 4, 15, 1), (600, 900, 3, 65, 2), (1000, 700, 3, 49, 3), (512, 400, 3, 3, 3),
              (512, 400, 3, 5, 4), (300, 333, 4, 11, 5), (644, 333, 3, 41, 3), (201, 257, 4, 21, 2), (700, 500, 3, 81, 3), (4096, 300, 1, 121, 2),
-             (640, 60, 3, 41, 3), (333, 517, 3, 41, 3), (2048, 200, 1, 49, 3), (700, 420, 3, 115, 2), (64, 200, 3, 7, 3), (44, 300, 3, 7, 3)]
+             (640, 60, 3, 41, 3), (333, 517, 3, 41, 3), (2048, 200, 1, 49, 3), (700, 420, 3, 115, 2), (64, 200, 3, 7, 3), (44, 300, 3, 7, 3),
+             (335, 200, 3, 41, 3), (1001, 300, 3, 113, 2), (46, 40, 3, 9, 3), (641, 100, 3, 41, 1), (3847, 40, 3, 41, 3), (2050, 70, 3, 99, 3)]
 
 
 @pytest.mark.parametrize("w,h,ch,ksize,passes", BX_SHAPES)
