@@ -1527,9 +1527,10 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         if (allow_fast && allow_wr && u8c3 && !ck && !(opts && opts->engine == BLUR_ENGINE_FFT_ROWS_FIRST)) {
             const FftFamilyChoice fc0 = fft_family_choice(rows, cols, p.sz);
             const bool whole = fc0.fits && ((opts && opts->engine == BLUR_ENGINE_FFT_WAVE_RESIDENT) || fc0.wr_pays);
-            // (measured on the reference's sweep, one image per call: from 17 MP on the tiled path is 1.06 .. 1.76 times faster than the
-            // run-time-planned kernels, below it up to 1.3 times slower: two launches per band and tile on images of a few hundred strips)
-            if (tile_points > 0 || (!whole && !fc0.old_both && static_cast<long long>(rows) * cols >= 16000000ll)) {
+            // (measured on the reference's sweep, one image per call, with the two-line column kernels that take columns of up to 4096
+            // points whole: from 10.5 MP on the tiled path is 1.08 .. 1.76 times faster than the run-time-planned kernels -- 10.5 .. 15.8
+            // MP: 29 .. 35 GP/s against 26 .. 28 --, at 9.4 MP 7 % slower: tools/tiled_compare.py)
+            if (tile_points > 0 || (!whole && !fc0.old_both && static_cast<long long>(rows) * cols >= 10000000ll)) {
                 const int rc = plan_tiled(ctx, rows, cols, sigma, quirk, tile_points, p);
                 if (rc == BLUR_OK) return BLUR_OK;
                 if (rc != BLUR_ERR_UNSUPPORTED) return rc;
