@@ -141,9 +141,13 @@ struct FxQuirk {
 };
 
 // qc[NCH xl + c] (xl = 0 .. 127; NCH = 3: c = 0 .. 2, NCH = 1: channel c0 only) = the column term of pixel x0 + xl, 0 right of the
-// image.  256 threads; `scratch` = LDS for NCH (128 + 2 pad) + 2 pad + 1 + 4 doubles; ends with a barrier, after which scratch is free
-// again and qc is valid.  One wave per SIMD hides no latency, so: independent loads in batches of eight, every value converted to
-// double ONCE when it enters LDS, and the convolution (in double, reflect-101 applied when the tile is filled) eight taps per trip.
+// image.  256 threads; `scratch` = LDS for NCH (128 + 2 pad) + 2 pad + 1 + 6 doubles and 3 (128 + 2 pad) + 4 ints; ends with a barrier,
+// after which scratch is free again and qc is valid.  One wave per SIMD hides no latency, and a workgroup's 128 + 2 pad columns x 3
+// channels x nbands parts are 26 000 values (4K, sigma 20): one dword per lane and load kept the CU's address unit busy for 3 us per
+// trip of 48 loads (round 4, first form).  So: the parts are read 16 bytes per lane -- the values of the image columns the window
+// maps to under reflect-101 are CONTIGUOUS in a band's row of cpart --, 17 bands of independent loads per trip, summed as integers
+// into LDS; the window (reflect-101 applied, converted to double ONCE) is filled from there; the convolution runs in double, eight
+// taps per trip.
 template <int NCH>
 __device__ __forceinline__ void fx_quirk_cols_tile(unsigned char* scratch, float* qc, const FxQuirk& q, int f, int x0, int c0, int cols, int pad, int tid)
 {
@@ -151,32 +155,32 @@ __device__ __forceinline__ void fx_quirk_cols_tile(unsigned char* scratch, float
     double* cc = reinterpret_cast<double*>(scratch);
     double* tp = cc + nval;
     double* zs = tp + ntap;
+    int* S = reinterpret_cast<int*>(zs + 4 + ((nval + ntap) & 1));          // 16-byte aligned
     const size_t bstride = static_cast<size_t>(q.cpitch);
-    {   // the tile: thread t owns values t + 256 v; the bands' parts in groups of BG, all NV x BG loads of a group in flight together
-        // (a loop of dependent waits costs one trip to L2 / the Infinity Cache per band: 1-2 us each at one wave per SIMD)
-        constexpr int NVMAX = NCH == 3 ? 4 : 2, BG = NCH == 3 ? 12 : 24;
-        const int* cp[NVMAX];
-        int sum[NVMAX];
+    // the image columns [xlo, xhi) that the window positions a valid output reads (x0 - pad .. min(x0 + 127, cols - 1) + pad) map to
+    const int wlo = x0 - pad, whi = min(x0 + kFxChunk, cols) + pad;
+    int xlo = max(wlo, 0), xhi = min(whi, cols);
+    if (wlo < 0) xhi = max(xhi, min(cols, 1 - wlo));                        // position x < 0 reads column -x
+    if (whi > cols) xlo = min(xlo, max(0, 2 * cols - 1 - whi));             // position x >= cols reads column 2 (cols - 1) - x
+    {
+        typedef int i4u __attribute__((ext_vector_type(4), aligned(4)));
+        typedef int i4 __attribute__((ext_vector_type(4)));
+        constexpr int BG = 17;
+        const int quads = (3 * (xhi - xlo) + 3) / 4;                        // (the last one may read up to 12 bytes of the next row / of zpart)
+        const int* base = q.cpart + static_cast<size_t>(f) * q.nbands * bstride + 3 * xlo;
+        for (int qd = tid; qd < quads; qd += 256) {
+            const int* cp = base + 4 * qd;
+            i4 sum = { 0, 0, 0, 0 };
+            for (int b0 = 0; b0 < q.nbands; b0 += BG) {
+                i4 t[BG];
 #pragma unroll
-        for (int v = 0; v < NVMAX; ++v) {
-            const int i = min(tid + 256 * v, nval - 1), p = i / NCH, ch = NCH == 3 ? i - 3 * p : c0;
-            cp[v] = q.cpart + static_cast<size_t>(f) * q.nbands * bstride + 3 * mx_refl(x0 - pad + p, cols) + ch;
-            sum[v] = 0;
+                for (int j = 0; j < BG; ++j) t[j] = *reinterpret_cast<const i4u*>(cp + static_cast<size_t>(min(b0 + j, q.nbands - 1)) * bstride);
+#pragma unroll
+                for (int j = 0; j < BG; ++j)
+                    if (b0 + j < q.nbands) sum += t[j];
+            }
+            *reinterpret_cast<i4*>(S + 4 * qd) = sum;
         }
-        for (int b0 = 0; b0 < q.nbands; b0 += BG) {
-            int t[NVMAX][BG];
-#pragma unroll
-            for (int j = 0; j < BG; ++j)
-#pragma unroll
-                for (int v = 0; v < NVMAX; ++v) t[v][j] = cp[v][static_cast<size_t>(min(b0 + j, q.nbands - 1)) * bstride];
-#pragma unroll
-            for (int j = 0; j < BG; ++j)
-#pragma unroll
-                for (int v = 0; v < NVMAX; ++v) sum[v] += b0 + j < q.nbands ? t[v][j] : 0;
-        }
-#pragma unroll
-        for (int v = 0; v < NVMAX; ++v)
-            if (tid + 256 * v < nval) cc[tid + 256 * v] = static_cast<double>(sum[v]);
     }
     for (int i = tid; i < ntap; i += 256) tp[i] = static_cast<double>(q.taps[i]);
     {   // Z: wave w < 3 adds up channel w's parts (exact integers), four independent loads per lane and trip, then across the wave
@@ -194,6 +198,12 @@ __device__ __forceinline__ void fx_quirk_cols_tile(unsigned char* scratch, float
             for (int o = 32; o >= 1; o >>= 1) z += __shfl_xor(z, o, 64);
             if (l == 0) zs[w] = static_cast<double>(z);
         }
+    }
+    __syncthreads();
+    for (int i = tid; i < nval; i += 256) {
+        const int p = i / NCH, ch = NCH == 3 ? i - 3 * p : c0;
+        const int xr = min(max(mx_refl(x0 - pad + p, cols), xlo), xhi - 1);     // (clamped: positions no valid output reads)
+        cc[i] = static_cast<double>(S[3 * (xr - xlo) + ch]);
     }
     __syncthreads();
     const double sp = (pad & 1) ? -1.0 : 1.0;
@@ -813,7 +823,10 @@ inline int fx_band_rows(int rows, int cols, int nframes, int num_cus)
     const int gpt = fx_groups_per_thread(cols);
     const long long nbatches = ((cols + 3) / 4 + 256 * gpt - 1) / (256 * (gpt > 0 ? gpt : 1));
     int br = kFxSumRows;
-    while (br < 128 && nbatches * ((rows + 2 * br - 1) / (2 * br)) * nframes >= 4ll * num_cus) br *= 2;
+#ifndef FX_BAND_WGS
+#define FX_BAND_WGS 4
+#endif
+    while (br < 128 && nbatches * ((rows + 2 * br - 1) / (2 * br)) * nframes >= static_cast<long long>(FX_BAND_WGS) * num_cus) br *= 2;
     return br;
 }
 
