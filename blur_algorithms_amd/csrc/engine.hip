@@ -1439,7 +1439,7 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
     //   | engine                      | where                                                   | measured (MI355X, 8 frames per call)            |
     //   | fused matrix-core kernel    | pad <= 72 (sigma <~ 22), non-negative taps with sum <= 1 | 4K sigma 20: 45 us per frame against 70 for the  |
     //   |                             | (any width, any pointer alignment)                      | two kernels and 105 for the FFT kernels          |
-    //   | fused kernel, wide windows  | pad 73 .. 168 on frames >= 6 MP (not where the next row | 4K sigma 30: 98 GP/s against 85 / 70; 8K sigma 40 |
+    //   | fused kernel, wide windows  | pad 73 .. 168 on frames >= 1 MP (not where the next row | 4K sigma 30: 98 GP/s against 85 / 70; 8K sigma 40 |
     //   |                             | applies), same conditions                               | single frame 79 against 54 / 26                   |
     //   | FFT, compile-time families  | frames < 1 MP, or pad > 136 on frames >= 6 MP           | 1080p sigma 20 single frame 72 / 78 us;          |
     //   |                             |                                                         | 4K sigma 50: 72 GP/s against 63                  |
@@ -1480,7 +1480,9 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         // above).
         const char* why = nullptr;
         if (fe && fe->nkb > 11 && choice == BLUR_ENGINE_AUTO) {
-            if (static_cast<long long>(rows) * cols < 6000000ll) { fe = nullptr; why = "wide fused kernel (pad 73 .. 168): frames below 6 MP run faster on two kernels"; }
+            // (round 4, segments of any number of tiles: one image per call, GP/s fused / two kernels / FFT: 1000 x 1500 sigma 38.7 21 / 21 / 16,
+            // 1600 x 2400 sigma 49 33 / 27 / 32, 1080p sigma 30 35 / 31 / 37, eight of them 69 / 63 / 63: from 1 MP on; rounds 3-4 had 6 MP here)
+            if (static_cast<long long>(rows) * cols < 1000000ll) { fe = nullptr; why = "wide fused kernel (pad 73 .. 168): frames below 1 MP run on two kernels or the FFT kernels"; }
             else if (small_fft && fe->nkb >= 23) { fe = nullptr; why = "wide fused kernel: pad > 152 where the FFT engine has a compile-time family for the frame"; }
         }
         if (!fe && !why) why = "fused matrix-core engine: no kernel instantiated for this pad";
@@ -1527,10 +1529,13 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         if (allow_fast && allow_wr && u8c3 && !ck && !(opts && opts->engine == BLUR_ENGINE_FFT_ROWS_FIRST)) {
             const FftFamilyChoice fc0 = fft_family_choice(rows, cols, p.sz);
             const bool whole = fc0.fits && ((opts && opts->engine == BLUR_ENGINE_FFT_WAVE_RESIDENT) || fc0.wr_pays);
-            // (measured on the reference's sweep, one image per call, with the two-line column kernels that take columns of up to 4096
-            // points whole: from 10.5 MP on the tiled path is 1.08 .. 1.76 times faster than the run-time-planned kernels -- 10.5 .. 15.8
-            // MP: 29 .. 35 GP/s against 26 .. 28 --, at 9.4 MP 7 % slower: tools/tiled_compare.py)
-            if (tile_points > 0 || (!whole && !fc0.old_both && static_cast<long long>(rows) * cols >= 10000000ll)) {
+            // (measured, one image per call, tools/tiled_compare.py: from 17 MP on the tiled path is 1.06 .. 1.76 times faster than the
+            // run-time-planned kernels in either orientation; between 10 and 16 MP only where the columns still fit one transform
+            // (rows + 2 pad <= 4096: wide images, 29 .. 35 GP/s against 26 .. 28) -- the reference's own sweep has tall images, whose
+            // columns then need two bands of 4096 points each: 5 .. 9 % slower than the run-time-planned kernels there)
+            const long long mp = static_cast<long long>(rows) * cols;
+            const bool pays = mp >= 16000000ll || (mp >= 10000000ll && rows + 2 * p.sz.pad <= 4096);
+            if (tile_points > 0 || (!whole && !fc0.old_both && pays)) {
                 const int rc = plan_tiled(ctx, rows, cols, sigma, quirk, tile_points, p);
                 if (rc == BLUR_OK) return BLUR_OK;
                 if (rc != BLUR_ERR_UNSUPPORTED) return rc;

@@ -1039,11 +1039,14 @@ template <int NKB> hipError_t fx_launch_u8(hipStream_t st, const uint8_t* src, u
     // Segments per strip of columns: a segment of t tiles takes t + NT steps (NT of run-in), and the chip runs num_cus tasks at a
     // time; take the number of segments with the shortest makespan = rounds x steps per task (one segment unless the strips
     // are too few to fill the chip: 240 strips of a 4K batch of 8 stay whole, a single 4K frame is cut in 8)
-    int nseg = 1, tps = ((g.ntiles + C::NT - 1) / C::NT) * C::NT;
+    int nseg = 1, tps = g.ntiles;
     {
+        // (any number of tiles per segment: the unrolled rotation of the accumulator tiles is relative to the segment's first step.
+        // Rounds 3-4 rounded it up to a multiple of NT for no reason the kernel has: 1080p, 8 frames, was cut in segments of 20 and 14
+        // tiles -- 25 steps -- instead of 17 and 17 -- 22 steps)
         long long best = -1;
-        for (int n = 1; n <= (g.ntiles + C::NT - 1) / C::NT; ++n) {
-            const int t = (((g.ntiles + n - 1) / n + C::NT - 1) / C::NT) * C::NT, ns = (g.ntiles + t - 1) / t;
+        for (int n = 1; n <= g.ntiles; ++n) {
+            const int t = (g.ntiles + n - 1) / n, ns = (g.ntiles + t - 1) / t;
             const long long rounds = (nstripes * ns + num_cus - 1) / num_cus, span = rounds * (t + C::NT);
             if (best < 0 || span < best) { best = span; nseg = ns; tps = t; }
         }

@@ -66,7 +66,7 @@ def test_every_instantiated_window(ctx, sigma, nkb):
 
 def test_the_librarys_choice_of_engine(ctx):
     """BLUR_ENGINE_AUTO (include/blur_amd.h): the fused matrix-core kernel (family 6) where the kernel's half width is at most 72
-    (any width, any pointer alignment), and its wide-window form (half widths 73 .. 168) on frames of 6 MP and more;
+    (any width, any pointer alignment), and its wide-window form (half widths 73 .. 168) on frames of 1 MP and more;
     else the two-kernel matrix engine (family 4) for frames of 1 MP and more whose kernel it can hold; the FFT kernels for pad > 168,
     for kernels with negative taps and for small frames or the widest windows where the FFT engine has a compile-time family.  The choice never depends on the number of frames.  Asking for an engine
     explicitly where it cannot run is an error."""
@@ -85,10 +85,12 @@ def test_the_librarys_choice_of_engine(ctx):
     assert fam() == 6
     ctx.pffft_(odd, 20.0)                                         # width 1921: the same kernel (any width since round 4)
     assert fam() == 6
-    ctx.pffft_(batch, 30.0)                                       # pad 98 on a 2 MP frame: the two kernels (the wide fused kernels from 6 MP)
-    assert fam() == 4
+    ctx.pffft_(batch, 30.0)                                       # pad 98 on a 2 MP frame: the wide fused kernel (from 1 MP since round 4)
+    assert fam() == 6
+    mid = torch.from_numpy(_rand_img(700, 1200, 2)).cuda()
+    ctx.pffft_(mid, 30.0)                                         # 0.84 MP: not the wide fused kernel
     code, note = ctx.last_engine()                                # blur_last_engine: what ran and why the faster engine was passed over
-    assert code == 4 and "two-kernel" in note and "not taken" in note and "6 MP" in note
+    assert code != 6 and "not taken" in note and "1 MP" in note
     ctx.pffft_(batch, 20.0)
     assert ctx.last_engine() == (6, "fused matrix-core kernel")
     ctx.pffft_(batch, 60.0)                                       # pad 195: beyond every matrix-core window

@@ -53,9 +53,9 @@ def test_tiled_path_in_place_and_batch(ctx):
 
 @pytest.mark.parametrize("rows,cols,sigma", [(5400, 3100, 60.0), (3200, 5200, 58.0), (2800, 4200, 64.8)])
 def test_the_librarys_choice_for_long_lines(ctx, rows, cols, sigma):
-    """kernels wider than 337 taps on images of 10 MP and more with a padded line longer than one wave-resident transform (4096 points):
-    the library's own choice is the tiled path (the third shape: columns whole on a two-line column kernel, rows in two tiles), and it
-    gives the oracle's bytes"""
+    """kernels wider than 337 taps with a padded line longer than one wave-resident transform (4096 points), on images of 16 MP and
+    more -- or of 10 MP and more while the columns still fit one transform (the third shape: columns whole on a two-line column
+    kernel, rows in two tiles): the library's own choice is the tiled path, and it gives the oracle's bytes"""
     import torch
     from oracle import oracle as O
     img = _rand_img(rows, cols, rows + cols)

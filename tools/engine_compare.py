@@ -6,7 +6,7 @@ import blur_algorithms_amd as B
 ctx = B.BlurContext(0)
 SHAPES = ((1000, 1500, 38.7, 1), (1600, 2400, 49.0, 1), (1080, 1920, 30.0, 1), (1080, 1920, 30.0, 8), (1080, 1920, 50.0, 8), (2160, 3840, 50.0, 1), (2160, 3840, 30.0, 1), (2160, 3840, 50.0, 8), (4320, 7680, 40.0, 1))
 if "--sweep" in sys.argv:      # the first sizes of the reference's own benchmark (Source.cpp:627-635): one image per call, sigma = sqrt(cols)
-    SHAPES = tuple((1000 + 150 * i, 1500 + 225 * i, (1500 + 225 * i) ** 0.5, 1) for i in range(12))
+    SHAPES = tuple((1500 + 225 * i, 1000 + 150 * i, (1500 + 225 * i) ** 0.5, 1) for i in range(12))      # tall: cv::Size(y, x), x > y
 for rows, cols, sigma, nf in SHAPES:
     img = torch.randint(0, 256, (nf, rows, cols, 3), dtype=torch.uint8, device="cuda")
     out = torch.empty_like(img)
