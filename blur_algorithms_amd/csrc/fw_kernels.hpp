@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
         rr[gq] = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
     };
     // C: column pass of step slot qs from hl (fx_kernels.hpp: colpass): first the tile that FINISHES, last the tile that STARTS
-    auto colpass = [&](int qs, int hb, auto beside) __attribute__((always_inline)) {
+    // `ri`: step ri of the segment's first NT (-1: a later step) -- the triples of tiles above the segment (a2 > ri) are left out
+    // statically (fx_kernels.hpp: colpass)
+    auto colpass = [&](int qs, int hb, int ri, auto beside) __attribute__((always_inline)) {
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
         mx_half8 v1[2], v2[2];
 #pragma unroll
@@ -246,12 +248,14 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
             const int d = dof(it);
             const int b = d & 1, a2 = d >> 1, slot = (qs - a2 + 2 * NT) % NT;
             if (it + 2 < NKB) tq[(it + 2) % 3] = tlo(dof(it + 2));
-            mx_float16 t = d == 0 ? zero : acc[slot];
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v1[b], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(tq[it % 3], v1[b], t, 0, 0, 0);
-            t = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v2[b], t, 0, 0, 0);
-            asm volatile("" : "+a"(t));          // pins the three products between this triple's fences
-            if (it == 0) tfin = t; else acc[slot] = t;
+            if (ri < 0 || a2 <= ri) {
+                mx_float16 t = d == 0 ? zero : acc[slot];
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v1[b], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(tq[it % 3], v1[b], t, 0, 0, 0);
+                t = __builtin_amdgcn_mfma_f32_32x32x16_f16(th[d], v2[b], t, 0, 0, 0);
+                asm volatile("" : "+a"(t));      // pins the three products between this triple's fences
+                if (it == 0) tfin = t; else acc[slot] = t;
+            }
             beside(it);
 #ifndef FW_NOSB
             __builtin_amdgcn_sched_barrier(0);
@@ -301,11 +305,8 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
     //   column pass the hand-off of step s + 1 (slots 0 .. 7, into hl[1]; copied to hl[0] at the end of the step), the emission of
     //               the tile this step finishes (slots 1 .. 4), window s + 2 group by group into the buffer window s left (from slot 5)
     // The step loop is unrolled NT times: the accumulator rotation is static, the window buffers alternate through a run-time offset.
-    for (int sb = s0; sb < s1; sb += NT) {
-#pragma unroll
-        for (int qs = 0; qs < NT; ++qs) {
-            const int s = sb + qs;
-            if (s >= s1) break;
+    auto step = [&](int s, int qs, int ri) __attribute__((always_inline)) {
+        {
             const int par = (s - s0) & 1;                      // window s: buffer par; window s + 1: the other one
             const int ptile = s - 1 - NT;
             const bool pvalid = ptile >= tile0 && s > s0;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
             rowpass(par ^ 1, [&](int kb) __attribute__((always_inline)) {
                 if (kb < 4) store_group(ptile, pvalid, kb);
             });
-            colpass(qs, 0, [&](int it) __attribute__((always_inline)) {
+            colpass(qs, 0, ri, [&](int it) __attribute__((always_inline)) {
                 if (it < 8) split_piece(par ^ 1, 1, it);
                 if (it >= 1 && it <= 4) emit_piece(it - 1);
                 if (it >= 5) {
@@ -327,6 +328,22 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
 #ifndef FW_ABL_NOBARRIER
             __syncthreads();                                   // window s + 2 complete, window s + 1 no longer read
 #endif
+        }
+    };
+    // the first NT steps of a segment as their own copy of the body, without the column products of the tiles above the segment (about
+    // half the column pass of these steps: NT = 11 for the widest window, where a single image's segments are 14 .. 20 steps long)
+#ifndef FW_NO_PEEL
+#pragma unroll
+    for (int j = 0; j < NT; ++j) step(s0 + j, j, j);
+    for (int sb = s0 + NT; sb < s1; sb += NT) {
+#else
+    for (int sb = s0; sb < s1; sb += NT) {
+#endif
+#pragma unroll
+        for (int qs = 0; qs < NT; ++qs) {
+            const int s = sb + qs;
+            if (s >= s1) break;
+            step(s, qs, -1);
         }
     }
     {

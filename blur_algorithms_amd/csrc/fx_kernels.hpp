@@ -528,7 +528,10 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     // tile that FINISHES with block 0 of this step (its window block NKB - 1), then blocks 2 .. NKB - 2 of the tiles in flight,
     // last blocks 0 and 1 of the tile that STARTS -- into the finished tile's registers, which E has read by then.  `beside(it)`
     // runs after triple it; a scheduling fence after every triple keeps the slices where they are.
-    auto colpass = [&](int c, int qs, auto beside) __attribute__((always_inline)) {
+    // `ri` (run-in): step ri of a segment's first NT (-1: any later step) -- tile s - a2 exists only for a2 <= ri, and the triples of
+    // the others are left out STATICALLY (the first NT steps are their own copy of the step body: a run-time test inside a slice
+    // would end the scheduling region; measured, 4.13 -> 5.53 us per step)
+    auto colpass = [&](int c, int qs, int ri, auto beside) __attribute__((always_inline)) {
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
         mx_half8 v1[2], v2[2];
 #pragma unroll
@@ -542,12 +545,14 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
         for (int it = 0; it < NKB; ++it) {
             const int d = it == 0 ? NKB - 1 : (it >= NKB - 2 ? it - (NKB - 2) : it + 1);
             const int b = d & 1, a2 = d >> 1, slot = (qs - a2 + 2 * NT) % NT;
-            fx_tile t = d == 0 ? zero : acc[c][slot];
-            fx_mma(th[d], v1[b], t, 0);
-            fx_mma(tl[d], v1[b], t, 1);
-            fx_mma(th[d], v2[b], t, 0);
-            FX_PIN(t);                           // pins the three products between this triple's fences
-            if (it == 0) tfin = t; else acc[c][slot] = t;
+            if (ri < 0 || a2 <= ri) {
+                fx_tile t = d == 0 ? zero : acc[c][slot];
+                fx_mma(th[d], v1[b], t, 0);
+                fx_mma(tl[d], v1[b], t, 1);
+                fx_mma(th[d], v2[b], t, 0);
+                FX_PIN(t);                       // pins the three products between this triple's fences
+                if (it == 0) tfin = t; else acc[c][slot] = t;
+            }
             beside(it);
 #ifdef FX_SGB
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -624,11 +629,8 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
 #else
 #define FX_STAMP(i)
 #endif
-    for (int sb = s0; sb < s1; sb += NT) {
-#pragma unroll
-        for (int qs = 0; qs < NT; ++qs) {
-            const int s = sb + qs;
-            if (s >= s1) break;
+    auto step = [&](int s, int qs, int ri) __attribute__((always_inline)) {
+        {
             const int cur = (s - s0) & 1;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
@@ -711,13 +713,30 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
                             }
                         }
                     };
-                    colpass(c, qs, beside);
+                    colpass(c, qs, ri, beside);
                 }
 #ifndef FX_NOSB
                 __builtin_amdgcn_sched_barrier(0);
 #endif
                 FX_STAMP(2 * c + 1)
             }
+        }
+    };
+    // the first NT steps of a segment (a segment has at least NT + 1): their own copy of the body, without the column products of the
+    // tiles above the segment (25 of the 55 triples of these steps per channel: 1.9 % of the matrix work of a 4K strip, 6 % of a
+    // 1080p half strip's); then the rotation starts over at slot 0
+#ifndef FX_NO_PEEL
+#pragma unroll
+    for (int j = 0; j < NT; ++j) step(s0 + j, j, j);
+    for (int sb = s0 + NT; sb < s1; sb += NT) {
+#else
+    for (int sb = s0; sb < s1; sb += NT) {
+#endif
+#pragma unroll
+        for (int qs = 0; qs < NT; ++qs) {
+            const int s = sb + qs;
+            if (s >= s1) break;
+            step(s, qs, -1);
         }
     }
     store_tile(s1 - 1 - NT, s1 - 1 - NT >= tile0);
