@@ -1487,7 +1487,8 @@ static int prepare(blur_ctx* ctx, int rows, int cols, double sigma, const blur_o
         }
         if (!fe && !why) why = "fused matrix-core engine: no kernel instantiated for this pad";
         // (0xfffffff0 is the offset the kernels give a dropped store: it must lie outside the frame's buffer resource)
-        else if (static_cast<long long>(rows) * cols * 3 > 0xfffffff0ll) why = "fused matrix-core engine: frame too large for 32-bit offsets";
+        // (and the left chunk's image resource starts 3 pad bytes before the frame: its size is the frame's plus those)
+        else if (static_cast<long long>(rows) * cols * 3 > 0xfffff000ll) why = "fused matrix-core engine: frame too large for 32-bit offsets";
         else if (quirk && fx_groups_per_thread(cols) == 0) why = "fused matrix-core engine: image wider than 16384 pixels (the quirk's pre-pass)";
         else if (quirk && cols < 4) why = "fused matrix-core engine: image narrower than 4 pixels (the quirk's pre-pass)";
         if (why && choice == BLUR_ENGINE_FUSED) return fail(ctx, BLUR_ERR_UNSUPPORTED, why);
@@ -1987,13 +1988,31 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
             ctx->fx_strips_bytes = bytes;
         }
     }
-    const int strip_blocks = (((rows + 3) / 4) * ((kFxChunk + 2 * pada) / 4) + 255) / 256, chunks_x = (cols + kFxChunk - 1) / kFxChunk;
+    // (the three-channel kernels read only the loads that touch a mirrored pixel from their strips: fx_strip_range)
+    const int chunks_x = (cols + kFxChunk - 1) / kFxChunk, narrow =
+#ifdef FX_FULL_STRIPS
+        0;
+#else
+        p.fx->nkb <= 11 ? 1 : 0;
+#endif
+    int strip_groups = (kFxChunk + 2 * pada) / 4;
+    if (narrow) {
+        const int gpr = strip_groups, per = (gpr + 7) / 8, nleft = fx_left_strips(pada);
+        strip_groups = 0;
+        for (int si = 0; si < nleft + g.nright; ++si) {
+            int lo, hi;
+            fx_strip_range(si < nleft ? si : chunks_x - g.nright + si - nleft, cols, pada, per, &lo, &hi);
+            strip_groups = std::max(strip_groups, std::min(8 * hi, gpr) - 8 * lo);
+        }
+        if (strip_groups < 1) strip_groups = 1;
+    }
+    const int strip_blocks = (((rows + 3) / 4) * strip_groups + 255) / 256;
     const int n_strip = strip_blocks * (fx_left_strips(pada) + g.nright) * nframes;
     FxQuirk qk{};
     if (!p.mx_quirk) {
         TimedLaunch t(ctx, 1, nframes);
         hipLaunchKernelGGL(fx_prepass<1>, dim3(n_strip), dim3(256), 0, ctx->stream, d_src, nullptr, nullptr, nullptr, ctx->fx_strips, rows, cols, p.sz.pad, pada, 1, 1, 0, chunks_x,
-                           g.nright, strip_blocks, kFxSumRows);
+                           g.nright, strip_blocks, kFxSumRows, narrow);
         HIP_TRY(ctx, hipGetLastError());
     }
     if (p.mx_quirk) {
@@ -2018,7 +2037,7 @@ static int run_fx_u8c3(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int 
           const int n_alt = nbands * nbatches * nframes;
           auto kern = gpt == 1 ? fx_prepass<1> : (gpt == 2 ? fx_prepass<2> : fx_prepass<4>);
           hipLaunchKernelGGL(kern, dim3(n_alt + n_strip), dim3(256), 0, ctx->stream, d_src, srow, cpart, zpart, ctx->fx_strips, rows, cols, p.sz.pad, pada, nbands,
-                             nbatches, n_alt, chunks_x, g.nright, strip_blocks, band_rows);
+                             nbatches, n_alt, chunks_x, g.nright, strip_blocks, band_rows, narrow);
           HIP_TRY(ctx, hipGetLastError()); }
         qk.srow_part = srow;
         qk.cpart = cpart;
@@ -2112,7 +2131,7 @@ static int run_wr_tiled(blur_ctx* ctx, const uint8_t* d_src, uint8_t* d_dst, int
         if (p.tl_quirk) {
             TimedLaunch t(ctx, 1, 1);
             const int n_alt = nbands * nbatches;
-            hipLaunchKernelGGL(fx_prepass<1>, dim3(n_alt), dim3(256), 0, ctx->stream, src, srow, cpart, zpart, nullptr, rows, cols, pad, 0, nbands, nbatches, n_alt, 1, 0, 1, band_rows);
+            hipLaunchKernelGGL(fx_prepass<1>, dim3(n_alt), dim3(256), 0, ctx->stream, src, srow, cpart, zpart, nullptr, rows, cols, pad, 0, nbands, nbatches, n_alt, 1, 0, 1, band_rows, 0);
             HIP_TRY(ctx, hipGetLastError());
             const int ne = (pitch + 255) / 256, nh = (rows + 255) / 256;
             const size_t lds = (static_cast<size_t>(3) * (256 + 2 * pad) + (2 * pad + 1) + 3 + 3 * 256) * sizeof(double);

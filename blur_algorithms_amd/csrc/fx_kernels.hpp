@@ -57,6 +57,19 @@ constexpr int kFxChunk = 128;     // pixel columns per workgroup
 constexpr int kFxMaxBatches = 4;  // column batches of the quirk's pre-pass = parts of a row's alternating sum (fx_prepass)
 // chunks at the left edge whose window (from 128 xc - pada) starts left of the image: they read a strip
 __host__ __device__ constexpr int fx_left_strips(int pada) { return pada > 0 ? (pada + kFxChunk - 1) / kFxChunk : 1; }
+// Which of a strip chunk's staging loads come from its strip (fx_blur_u8, round 4): thread (row, g0) loads the 12-byte groups g0 + 8 k,
+// k = 0 .. per - 1, of a window row, and a load instruction has ONE buffer resource -- so the strip holds the groups of whole k:
+// k in [*lo, *hi) (every group with a mirrored pixel lies in there), and the other k read the image itself.  For the 4K frame's
+// left chunk that is 24 of 68 groups (72 mirrored pixels + 24 copied ones) instead of the whole 272-pixel window.
+__host__ __device__ inline void fx_strip_range(int xc, int cols, int pada, int per, int* lo, int* hi)
+{
+    const int x0 = kFxChunk * xc;
+    const bool left = x0 - pada < 0, right = x0 + kFxChunk + pada > cols;
+    if (left && right) { *lo = 0; *hi = per; }
+    else if (left) { const int gl = (pada - x0 + 3) / 4; const int h = (gl + 7) / 8; *lo = 0; *hi = h < per ? h : per; }     // groups below gl hold a pixel < 0
+    else if (right) { const int gb = (cols - (x0 - pada)) / 4; *lo = gb / 8; *hi = per; }                                   // groups from gb on hold a pixel >= cols
+    else { *lo = 0; *hi = 0; }
+}
 
 template <int NKB> struct FxCfg {
     static constexpr int PADA = 8 * (NKB - 2), WIN = kFxChunk + 2 * PADA, GPR = WIN / 4, PER = (GPR + 7) / 8;
@@ -326,12 +339,23 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     // fx_edge_strips before the launch (left + nright strips per frame) -- and every other chunk's window lies inside the image.  So a
     // window row is 17 x 4 twelve-byte groups at base + row * pitch for every workgroup; the source is a buffer resource (groups
     // past the end of the last row read as zero; they only meet zero taps).
+    // Round 4: the strip of such a chunk holds only the staging loads (whole k) that touch a mirrored pixel -- fx_strip_range: k in
+    // [ka_lo, ka_hi) -- and the chunk's other loads read the image like everybody else's (two resources, chosen per load
+    // instruction by a wave-uniform test): a third of the strips' bytes, which the pre-pass writes at the memory's copy rate.
     constexpr int NLEFT = fx_left_strips(PADA);
     const int sidx = xc < NLEFT ? xc : (xc >= chunks - g.nright ? NLEFT + xc - (chunks - g.nright) : -1);      // uniform
-    const uint32_t pitch = sidx >= 0 ? 3u * C::WIN : 3u * static_cast<uint32_t>(g.cols);
-    const uint8_t* wbase = sidx >= 0 ? strips + (static_cast<size_t>(f) * (NLEFT + g.nright) + sidx) * g.rows * (3 * C::WIN) : img + 3 * (x0 - PADA);
-    const uint32_t wbytes = sidx >= 0 ? static_cast<uint32_t>(g.rows) * 3u * C::WIN : (static_cast<uint32_t>(g.rows) * g.cols - static_cast<uint32_t>(x0 - PADA)) * 3u;
-    const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wbase), 0, wbytes, kMxRsrcWord3);
+    int ka_lo = 0, ka_hi = 0;
+#ifdef FX_FULL_STRIPS
+    if (sidx >= 0) ka_hi = PER;
+#else
+    if (sidx >= 0) fx_strip_range(xc, g.cols, PADA, PER, &ka_lo, &ka_hi);
+#endif
+    const uint32_t pitch_s = 3u * C::WIN, pitch_i = 3u * static_cast<uint32_t>(g.cols);
+    const uint8_t* ibase = img + 3 * (x0 - PADA);               // (before the frame for the left chunk: its loads below ka_hi never use it)
+    const uint32_t ibytes = (static_cast<uint32_t>(g.rows) * g.cols - static_cast<uint32_t>(x0 - PADA)) * 3u;
+    const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(ibase), 0, ibytes, kMxRsrcWord3);
+    const __amdgpu_buffer_rsrc_t rstrip = sidx >= 0 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(strips + (static_cast<size_t>(f) * (NLEFT + g.nright) + sidx) * g.rows * (3 * C::WIN)),
+                                                                                        0, static_cast<uint32_t>(g.rows) * 3u * C::WIN, kMxRsrcWord3) : rimg;
     // staging map: a thread owns the 12-byte groups g0 + 8 k of window row `srow`.  ds_write_b64 is served in groups of 16 lanes over 32
     // banks: the two rows of a group must lie 16 banks apart, and the row pitch is 4 mod 8 dwords, so they are rows a and a + 4
     // (a wave still covers 8 consecutive rows: its loads are 8 rows x 96 contiguous bytes as before)
@@ -346,12 +370,16 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
         if (s >= 0) return;
 #endif
         const int r = mx_refl(32 * s - PADA + row, g.rows);
-        const uint32_t off = static_cast<uint32_t>(r) * pitch + 12u * g0;
+        const uint32_t off_i = static_cast<uint32_t>(r) * pitch_i + 12u * g0, off_s = static_cast<uint32_t>(r) * pitch_s + 12u * g0;
         typedef uint32_t u3 __attribute__((ext_vector_type(3)));
 #pragma unroll
         for (int k = 3 * j; k < 3 * j + 3 && k < PER; ++k) {
             const bool in = (C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8;
-            const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rimg, in ? off + 96u * k : off, 0, 0);
+            const bool from_strip = k >= ka_lo && k < ka_hi;                                 // wave-uniform
+            const uint32_t off = from_strip ? off_s : off_i;
+            // (lanes whose group lies past the window's GPR -- the last k only -- repeat the group of the k before: a valid address in
+            // either resource; the row's first groups are not, for the left chunk's image resource: it starts before the frame)
+            const u3 t = __builtin_amdgcn_raw_buffer_load_b96(from_strip ? rstrip : rimg, off + 96u * (in ? k : (k > 0 ? k - 1 : 0)), 0, 0);
             raw.d[k][0] = t[0]; raw.d[k][1] = t[1]; raw.d[k][2] = t[2];
         }
         if (QUIRK && j == 0) {
@@ -775,15 +803,23 @@ inline int fx_right_strips(int cols, int pada)
 // lies inside the image (one 12-byte load), is the pixel-reversed copy of 4 adjacent image pixels (one 12-byte load, three
 // v_perm_b32), or -- image widths that are not multiples of 4, tiny images -- straddles an edge and is gathered pixel by pixel.
 // work items (fx_prepass): blocks over ceil(rows / 4) x win / 4 threads (4 rows of one group each) x strips x frames
+// narrow (fx_blur_u8's strips): only the groups of fx_strip_range are written (the kernel reads the others from the image)
 __device__ __forceinline__ void fx_edge_strips_body(const uint8_t* __restrict__ src, uint8_t* __restrict__ strips, int rows, int cols, int pada, int chunks, int nright,
-                                                    int bx, int sidx, int f)
+                                                    int bx, int sidx, int f, int narrow)
 {
     const int win = kFxChunk + 2 * pada, gpr = win / 4;
     const int nleft = fx_left_strips(pada);
     const int xc = sidx < nleft ? sidx : chunks - nright + sidx - nleft, x0 = kFxChunk * xc;
+    int glo = 0, gn = gpr;
+    if (narrow) {
+        int lo, hi;
+        fx_strip_range(xc, cols, pada, (gpr + 7) / 8, &lo, &hi);
+        glo = 8 * lo;
+        gn = min(8 * hi, gpr) - glo;
+    }
     const int i = bx * 256 + threadIdx.x, rq = (rows + 3) / 4;
-    if (i >= rq * gpr) return;
-    const int r4 = i / gpr, gidx = i - r4 * gpr;
+    if (i >= rq * gn) return;
+    const int r4 = i / gn, gidx = glo + i - r4 * gn;
     const int X = x0 - pada + 4 * gidx;
     const bool mir = X < 0 || X >= cols;
     const int xs = X < 0 ? -X - 3 : (X >= cols ? 2 * cols - 5 - X : X);
@@ -1012,7 +1048,7 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
 template <int G>
 __global__ __launch_bounds__(256) void fx_prepass(const uint8_t* __restrict__ src, int* __restrict__ srow_part, int* __restrict__ cpart, long long* __restrict__ zpart,
                                                   uint8_t* __restrict__ strips, int rows, int cols, int pad, int pada, int nbands, int nbatches, int n_alt, int chunks,
-                                                  int nright, int strip_blocks, int band_rows)
+                                                  int nright, int strip_blocks, int band_rows, int narrow)
 {
     __shared__ int sred[kFxSumRows][3][64];
     int b = blockIdx.x;
@@ -1022,7 +1058,7 @@ __global__ __launch_bounds__(256) void fx_prepass(const uint8_t* __restrict__ sr
     } else {
         b -= n_alt;
         const int nstrips = fx_left_strips(pada) + nright, bx = b % strip_blocks, sidx = (b / strip_blocks) % nstrips, f = b / (strip_blocks * nstrips);
-        fx_edge_strips_body(src, strips, rows, cols, pada, chunks, nright, bx, sidx, f);
+        fx_edge_strips_body(src, strips, rows, cols, pada, chunks, nright, bx, sidx, f, narrow);
     }
 }
 #endif  // BLUR_FX_QUIRK_KERNELS
