@@ -940,7 +940,10 @@ __device__ __forceinline__ void fx_altsums_body(const uint8_t* __restrict__ src,
         for (int j = 0; j < G; ++j)
 #pragma unroll
             for (int k = 0; k < 6; ++k) accp[j][k] = accn[j][k] = 0;
-        constexpr int RB = G == 1 ? 8 : (G == 2 ? 4 : 2);                 // rows of loads in flight (RB G loads of 12 bytes per thread)
+#ifndef FX_PRE_RB
+#define FX_PRE_RB 8
+#endif
+        constexpr int RB = G == 1 ? FX_PRE_RB : (G == 2 ? 4 : 2);         // rows of loads in flight (RB G loads of 12 bytes per thread)
         for (int rb = rs; rb < re; rb += RB) {
             u3 d[RB][G];
 #pragma unroll

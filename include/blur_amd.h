@@ -42,7 +42,7 @@ typedef struct blur_ctx blur_ctx;
    about speed and about what each engine can hold.  engine.hip: prepare() holds the policy table of BLUR_ENGINE_AUTO. */
 enum blur_engine {
     BLUR_ENGINE_AUTO = 0,            /* fused matrix-core kernel where it exists for the kernel's half width (pad <= 72; pad <= 168
-                                        on frames of 6 MP and more; any image width, any pointer alignment); else the two-kernel
+                                        on frames of 1 MP and more; any image width, any pointer alignment); else the two-kernel
                                         matrix-core engine (pad <= 168, non-negative taps) except where the FFT engine has a faster
                                         compile-time family (small frames, the widest kernels on 4K frames); else FFT.  The choice
                                         depends on rows, cols and the kernel only: never on the number of frames, on where the
@@ -125,7 +125,7 @@ const char* blur_last_error(const blur_ctx* ctx);
 /* which kernels the last u8c3 blur on this ctx ran on: returns 0 run-time-planned FFT, 1 specialised rows-first FFT, 2 wave-resident
    FFT, 3 whole-image 2D FFT, 4 two-kernel matrix-core engine, 6 fused matrix-core kernel (-1: none yet), and writes into note
    (n bytes, may be NULL) the engine's name and, under BLUR_ENGINE_AUTO, why a faster engine was passed over -- e.g.
-   "two-kernel matrix-core engine (not taken: wide fused kernel (pad 73 .. 168): frames below 6 MP run faster on two kernels)" */
+   "two-kernel matrix-core engine (not taken: wide fused kernel (pad 73 .. 168): frames below 1 MP run on two kernels or the FFT kernels)" */
 int blur_last_engine(const blur_ctx* ctx, char* note, size_t n);
 
 /* Per-kernel timing with HIP events on the ctx's stream.  While enabled, every launch
