@@ -121,8 +121,8 @@ def fused_launch_shape(rows, cols, pad, frames, num_cus=256):
     wide = nkb > 11                                   # fw_kernels.hpp: one channel per workgroup, so three times the tasks
     stripes = chunks * frames * (3 if wide else 1)
     best = None
-    for n in range(1, -(-ntiles // nt) + 1):
-        t = -(-(-(-ntiles // n)) // nt) * nt
+    for n in range(1, ntiles + 1):
+        t = -(-ntiles // n)                          # (round 4: any number of tiles per segment)
         ns = -(-ntiles // t)
         span = -(-stripes * ns // num_cus) * (t + nt)
         if best is None or span < best[0]:
@@ -130,7 +130,9 @@ def fused_launch_shape(rows, cols, pad, frames, num_cus=256):
     _, nseg, tps = best
     steps = sum(min(tps, ntiles - sg * tps) + nt for sg in range(nseg))          # per strip of columns
     mfma_per_wave_step = (1 if wide else 3) * 5 * nkb                            # channels x (2 row + 3 column products) x window blocks
-    mfmas = stripes * 4 * (steps * mfma_per_wave_step + nseg * 2 * nkb)          # 4 waves per task; the prologue's first row pass
+    # 4 waves per task; the prologue's first row pass; round 4: the first nt steps of a segment leave out the column products of the
+    # tiles above it (nt^2 triples of three products per channel; SQ_INSTS_MFMA of profiles/r04fx_sq_counters.json agrees)
+    mfmas = stripes * 4 * (steps * mfma_per_wave_step + nseg * 2 * nkb - nseg * (1 if wide else 3) * 3 * nt * nt)
     return {"nkb": nkb, "tasks": stripes * nseg, "segments_per_strip": nseg, "steps_per_strip": steps, "mfma_instructions": mfmas,
             "flops": mfmas * 2 * 32 * 32 * 16}
 
@@ -231,7 +233,7 @@ def box_leg(ctx, torch, dev, steps, warmup, copy=False):
            "dtype": "u8 (i8 matrix-core sums in i32, 24-bit multiply-high rounding per sweep)", "data": "synthetic",
            "config": {"workload": c["label"] + ", in place, device-resident", "frames_per_gpu": 1},
            "ms_per_step_gpu": percentiles(per_step),      # of a second pass of the same K steps with one event per step
-           "roofline": {"bound": "hbm", "kernel": "bx_margins_kernel + bx_horz_kernel<3,3,1> + bx_vert_kernel<1,3,4> (whole call)", "achieved": round(achieved, 1),
+           "roofline": {"bound": "hbm", "kernel": "bx_horz3_kernel<1,3> + bx_vert_kernel<1,3,4> (whole call)", "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "alg_bytes_per_launch": moved,
                         "two_pass_equiv": {"bytes_per_launch": equiv, "achieved": round(equiv / (ms * 1e-3) / 1e9, 1),
                                            "frac": round(equiv / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}}
