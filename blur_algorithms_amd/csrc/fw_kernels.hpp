@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
     if (QUIRK) {
         // the column term of this chunk's pixels in the task's channel (fx_kernels.hpp: fx_quirk_cols_tile; the window buffers are
         // not in use yet: tile and taps in buffer 0, the result in buffer 1)
+        static_assert(C::BUF >= 8 * (C::WIN + 2 * C::PADA + 1 + 6) + 4 * (3 * C::WIN + 4), "fx_quirk_cols_tile's scratch fits window buffer 0");
         float* qc = reinterpret_cast<float*>(fw_lds + C::BUF);
         fx_quirk_cols_tile<1>(fw_lds, qc, qk, f, x0, c, g.cols, g.pad, tid);
         const float v = qc[32 * wave + m];

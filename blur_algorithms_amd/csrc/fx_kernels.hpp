@@ -298,6 +298,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     float cpos[3], cneg[3];
     if (QUIRK) {
         // the column term of this chunk's pixels (nothing else uses LDS yet: tile and taps in window buffer 0, the result in buffer 1)
+        static_assert(C::BUF >= 8 * (3 * C::WIN + 2 * PADA + 1 + 6) + 4 * (3 * C::WIN + 4), "fx_quirk_cols_tile's scratch fits window buffer 0");
         float* qc = reinterpret_cast<float*>(fx_lds + C::BUF);
         fx_quirk_cols_tile<3>(fx_lds, qc, qk, f, x0, 0, g.cols, g.pad, tid);
 #pragma unroll

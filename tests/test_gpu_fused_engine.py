@@ -210,6 +210,23 @@ def test_fused_engine_any_width(ctx, rows, cols, sigma, quirk):
     assert bool((buf[img.size:] == 0xA5).all())
 
 
+# Widths around every way a chunk of 128 columns can meet the image's edges (round 4: an edge chunk's strip holds only the staging
+# loads that touch a mirrored pixel -- fx_strip_range -- and its other loads read the image): one chunk that is left and right edge at
+# once, a right edge that cuts the last chunk after 1 .. 127 columns, two chunks whose windows reach past the right edge, windows
+# that end exactly at the edge; a narrow window (sigma 6: pad 19) where the strip is a single staging load.
+@pytest.mark.parametrize("cols,sigma", [(129, 20.0), (136, 20.0), (199, 20.0), (200, 20.0), (201, 20.0), (255, 20.0), (256, 20.0), (257, 20.0), (272, 20.0),
+                                        (328, 20.0), (329, 20.0), (400, 20.0), (513, 20.0), (641, 20.0), (130, 6.0), (260, 6.0), (300, 12.0)])
+def test_fused_engine_edge_strips(ctx, cols, sigma):
+    from oracle import oracle as O
+    torch = _torch()
+    rows = 67
+    img = _rand_img(rows, cols, 31 * cols)
+    want, planes = O.pffft_blur_u8c3_f64(img, sigma, quirk=True, want_planes=True)
+    got = ctx.pffft_(torch.from_numpy(img).cuda(), sigma).cpu().numpy()
+    assert _fam(ctx) == 6
+    assert_u8_parity(got, want, planes)
+
+
 @pytest.mark.parametrize("off_in,off_out", [(1, 0), (2, 3), (3, 1), (0, 2)])
 @pytest.mark.parametrize("cols", [332, 333, 646])
 def test_fused_engine_any_alignment(ctx, off_in, off_out, cols):
