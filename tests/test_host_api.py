@@ -284,3 +284,29 @@ def test_mx_fragments_are_the_toeplitz_band_in_two_halves():
                 assert np.all(np.abs(fr[0, kb, l] + fr[1, kb, l] - want) <= np.maximum(np.abs(want) * 2.0 ** -21, 2.0 ** -24))
     assert lib.blur_mx_fragments(taps.ctypes.data, 65, 10, out.ctypes.data) != 0      # window too small for the taps
     assert lib.blur_mx_window_blocks(65) == 11
+
+
+def test_bench_model_of_the_fused_launch():
+    """bench.py prices the fused kernel's `roofline` on the matrix instructions it executes; its model of the launch (segments of any
+    number of tiles, the first NT steps of a segment without the column products of tiles above it) must agree with the kernel:
+    pinned to SQ_INSTS_MFMA of the committed counter profile of the metric's launch (profiles/r04fx_sq_counters.json)"""
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    shape = bench.fused_launch_shape(2160, 3840, 65, 8)
+    assert (shape["nkb"], shape["tasks"], shape["segments_per_strip"], shape["steps_per_strip"]) == (11, 240, 1, 73)
+    counters = json.load(open(os.path.join(root, "profiles", "r04fx_sq_counters.json")))
+    counters = counters.get("fx_blur_u8", counters)
+    assert shape["mfma_instructions"] == int(counters["SQ_INSTS_MFMA"])
+    assert shape["flops"] == shape["mfma_instructions"] * 32768
+    # eight 1080p frames: 120 strips cut in two segments of 17 tiles (22 steps each), not 20 + 14
+    c2 = bench.fused_launch_shape(1080, 1920, 65, 8)
+    assert (c2["tasks"], c2["segments_per_strip"], c2["steps_per_strip"]) == (240, 2, 44)
+    # one 4K frame: 30 strips in 8 segments of 9 / 5 tiles; the wide kernels: one channel per task
+    one = bench.fused_launch_shape(2160, 3840, 65, 1)
+    assert one["tasks"] == 240 and one["segments_per_strip"] == 8
+    wide = bench.fused_launch_shape(2160, 3840, 165, 8)
+    assert wide["nkb"] == 23 and wide["tasks"] == 720
