@@ -295,23 +295,7 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     const int xpix = x0 + 32 * wave + 4 * Q;                       // first of the lane's 4 pixels after the transposes
     const bool in_cols = xpix + 3 < g.cols;                        // the whole quad lies inside the image: one 12-byte store
     const int tail_bytes = RAGGED && !in_cols && xpix < g.cols ? 3 * (g.cols - xpix) : 0;       // 3, 6 or 9 bytes of a quad cut by the right edge
-    float cpos[3], cneg[3];
-    if (QUIRK) {
-        // the column term of this chunk's pixels (nothing else uses LDS yet: tile and taps in window buffer 0, the result in buffer 1)
-        static_assert(C::BUF >= 8 * (3 * C::WIN + 2 * PADA + 1 + 6) + 4 * (3 * C::WIN + 4), "fx_quirk_cols_tile's scratch fits window buffer 0");
-        float* qc = reinterpret_cast<float*>(fx_lds + C::BUF);
-        fx_quirk_cols_tile<3>(fx_lds, qc, qk, f, x0, 0, g.cols, g.pad, tid);
-#pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float v = qc[3 * (32 * wave + m) + c];
-            cpos[c] = 0.5f + v;
-            cneg[c] = 0.5f - v;
-        }
-        __syncthreads();                                   // before the staging writes windows over it
-    } else {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) cpos[c] = cneg[c] = 0.5f;
-    }
+    float cpos[3], cneg[3];          // set in the prologue below, after the first window's loads are on their way
     const int qrows = 32 * (g.ntiles + NT);
     const double qrs = QUIRK ? static_cast<double>(qk.dr) * ((g.pad & 1) ? -1.0 : 1.0) : 0.0;
 
@@ -639,6 +623,23 @@ __global__ __launch_bounds__(256, 1) void fx_blur_u8(const uint8_t* __restrict__
     // window s0 + 2, as the loop expects them; R and S of the first product done
 #pragma unroll
     for (int j = 0; j < 3; ++j) issue_chunk(s0, j);
+    // (the quirk's column term while those loads travel: it works in LDS that the commits below overwrite)
+    if (QUIRK) {
+        // the column term of this chunk's pixels (nothing else uses LDS yet: tile and taps in window buffer 0, the result in buffer 1)
+        static_assert(C::BUF >= 8 * (3 * C::WIN + 2 * PADA + 1 + 6) + 4 * (3 * C::WIN + 4), "fx_quirk_cols_tile's scratch fits window buffer 0");
+        float* qc = reinterpret_cast<float*>(fx_lds + C::BUF);
+        fx_quirk_cols_tile<3>(fx_lds, qc, qk, f, x0, 0, g.cols, g.pad, tid);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = qc[3 * (32 * wave + m) + c];
+            cpos[c] = 0.5f + v;
+            cneg[c] = 0.5f - v;
+        }
+        __syncthreads();                                   // before the staging writes windows over it
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) cpos[c] = cneg[c] = 0.5f;
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) commit_chunk(0, j);
     issue_chunk(s0 + 1, 0);
