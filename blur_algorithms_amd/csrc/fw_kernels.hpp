@@ -18,14 +18,22 @@
 #include <type_traits>
 
 #ifndef FW_TL_REGS
-#define FW_TL_REGS 8      // lo halves of the fragments kept in registers (the others are read from LDS at every use)
+#define FW_TL_REGS 12     // lo halves of the fragments kept in registers (the others are read from LDS at every use; 8 -> 12 in round 4: +1.5 % at 4K, 16 the same)
 #endif
 
 namespace blur_amd {
 
 template <int NKB> struct FwCfg {
     static constexpr int PADA = 8 * (NKB - 2), WIN = kFxChunk + 2 * PADA, GPR = WIN / 4, PER = (GPR + 7) / 8;
-    static constexpr int PW = mx_row_pitch(NKB);                     // halfs per LDS row of the window
+    // halfs per LDS row of the window: every thread commits PER groups of 4 positions, 32 apart, without a lane mask (fx_kernels.hpp:
+    // FxCfg -- a masked commit is a branch in the middle of a slice of matrix instructions), so a row holds 32 PER positions; the
+    // pitch is 4 mod 8 dwords (conflict-free ds_read_b128, and ds_write_b64 with the staging rows of a 16-lane group 4 apart)
+    static constexpr int fw_pitch() { int dw = 16 * PER; while ((dw & 7) != 4) ++dw; return 2 * dw; }
+#ifdef FW_MASKED_COMMITS      // (rounds 3-4 A/B: lane-masked commits, the row term by threads 0 .. 31 only, the window's own pitch)
+    static constexpr int PW = mx_row_pitch(NKB);
+#else
+    static constexpr int PW = fw_pitch();
+#endif
     static constexpr int NT = (NKB - 1) / 2;                          // live accumulator tiles = steps per unrolled round
     static constexpr int BUF = 32 * PW * 2;                           // bytes of one window buffer (one channel)
     static constexpr int TLOFF = 2 * BUF;                             // lo halves of the fragments: [NKB][64 lanes] x 16 bytes
@@ -97,7 +105,11 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
     const uint8_t* wbase = sidx >= 0 ? strips + (static_cast<size_t>(f) * (NLEFT + g.nright) + sidx) * g.rows * (3 * C::WIN) : img + 3 * (x0 - PADA);
     const uint32_t wbytes = sidx >= 0 ? static_cast<uint32_t>(g.rows) * 3u * C::WIN : (static_cast<uint32_t>(g.rows) * g.cols - static_cast<uint32_t>(x0 - PADA)) * 3u;
     const __amdgpu_buffer_rsrc_t rimg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(wbase), 0, wbytes, kMxRsrcWord3);
+#ifdef FW_STAGE_LINEAR
     const int srow = tid >> 3, g0 = tid & 7;
+#else
+    const int srow = 8 * (tid >> 6) + ((tid >> 4) & 3) + 4 * ((tid >> 3) & 1), g0 = tid & 7;      // (fx_kernels.hpp: the staging map)
+#endif
     uint32_t raw[PER][3];
     int qpart[kFxMaxBatches] = {};
     // the window of step s: thread t moves the twelve-byte groups (t & 7) + 8 k of row t >> 3, all requested at once (consumed one
@@ -115,9 +127,13 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
             const u3 t = __builtin_amdgcn_raw_buffer_load_b96(rimg, in ? off + 96u * k : off, 0, 0);
             raw[k][0] = t[0]; raw[k][1] = t[1]; raw[k][2] = t[2];
         }
-        if (QUIRK && tid < 32)          // the row term of row re of V (= image row refl(re - PADA)): dr (-1)^pad Srow
-        {
-            const int* sp = qk.srow_part + (static_cast<size_t>(f) * qk.nbatches * g.rows + mx_refl(min(32 * s + tid, qrows - 1) - PADA, g.rows)) * 3 + c;
+#ifdef FW_MASKED_COMMITS
+        if (QUIRK && tid < 32)
+#else
+        if (QUIRK)                      // the row term of row re of V (= image row refl(re - PADA)): dr (-1)^pad Srow; every thread (row tid & 31:
+#endif
+        {                               // eight copies of each value) -- a test on tid would be a branch in the middle of a slice of matrix instructions
+            const int* sp = qk.srow_part + (static_cast<size_t>(f) * qk.nbatches * g.rows + mx_refl(min(32 * s + (tid & 31), qrows - 1) - PADA, g.rows)) * 3 + c;
 #pragma unroll
             for (int b = 0; b < kFxMaxBatches; ++b) qpart[b] = sp[static_cast<size_t>(min(b, qk.nbatches - 1)) * g.rows * 3];      // (fx_kernels.hpp: issue_chunk)
         }
@@ -131,7 +147,10 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
         if (buf >= 0) return;
 #endif
         if (k >= PER) return;
-        if ((C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8) {
+#ifdef FW_MASKED_COMMITS
+        if ((C::GPR % 8 == 0) || k < PER - 1 || g0 < C::GPR % 8)
+#endif
+        {   // (groups past the window's GPR of the last k hold whatever their clamped load returned: they land in the row's padding)
             _Float16* base = reinterpret_cast<_Float16*>(fw_lds + buf * C::BUF) + srow * PW + 4 * g0;
             uint2 wd;
             wd.x = __builtin_amdgcn_perm(raw[k][1], raw[k][0], selA);
@@ -140,12 +159,16 @@ __global__ __launch_bounds__(256, 1) void fw_blur_u8(const uint8_t* __restrict__
         }
     };
     auto commit_q = [&](int buf) __attribute__((always_inline)) {
+#ifdef FW_MASKED_COMMITS
         if (QUIRK && tid < 32) {
+#else
+        if (QUIRK) {                     // (every thread: the eight threads of a row store the same value to the same place)
+#endif
             int v = qpart[0];
 #pragma unroll
             for (int b = 1; b < kFxMaxBatches; ++b) v += b < qk.nbatches ? qpart[b] : 0;
             const float qraw = static_cast<float>(qrs * v);
-            float* qs = reinterpret_cast<float*>(fw_lds + C::QOFF) + buf * 64 + tid;
+            float* qs = reinterpret_cast<float*>(fw_lds + C::QOFF) + buf * 64 + (tid & 31);
             qs[0] = qraw;            // the term enters as qrow (-1)^x: lanes of even x read this copy,
             qs[32] = -qraw;          // lanes of odd x this one
         }

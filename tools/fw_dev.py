@@ -1,5 +1,5 @@
 """tools/fw_dev.py -- the wide fused matrix-core kernels (csrc/fw_kernels.hpp) against the float64 oracle (small shapes) and the two-kernel
-matrix engine (large ones): bytes, then time on 8 x 4K frames for a few sigmas.   usage: python tools/fw_dev.py [--no-check] [--quirk0]"""
+matrix engine (large ones): bytes, then time on 8 x 4K frames for a few sigmas.   usage: python tools/fw_dev.py [--no-check] [--quirk0] [--fused-only] [--s50]"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -38,7 +38,7 @@ frames = torch.randint(0, 256, (nf, rows, cols, 3), dtype=torch.uint8, device="c
 out = torch.empty_like(frames)
 for sigma in ((50.0,) if "--s50" in sys.argv else (26.0, 30.0, 36.0, 44.0, 50.0)):
     line = "4K x 8 sigma %.0f (pad %d):" % (sigma, B.pffft_sizing(rows, cols, sigma)["pad"])
-    for eng in (("fused",) if "--s50" in sys.argv else ("fused", "matrix", "fft")):
+    for eng in (("fused",) if ("--s50" in sys.argv or "--fused-only" in sys.argv) else ("fused", "matrix", "fft")):
         for _ in range(3):
             ctx.pffft_(frames, sigma, out=out, nyquist_quirk=quirk, engine=eng)
         torch.cuda.synchronize()
