@@ -401,10 +401,16 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
     wr_piece pfu[KU];
     const size_t frame_bytes = static_cast<size_t>(term.band_step > 0 ? term.band_step : rows) * cols * CH;     // bands of one image overlap in memory
     const int npiece = rows * PIECES;
-    auto strip_fast = [&](int uu) { const int ss = uu % nstrips; return aligned8 != 0 && (ss + 1) * G <= cols; };
+    // 1: a whole strip; 2: the last strip of an image whose width is no multiple of G -- its pieces reach into the next row: the same
+    // loads, the bytes right of the image masked when they are committed, the LAST row (whose pieces would leave the frame) byte by
+    // byte; 0: byte by byte altogether.  (Until round 4 every ragged strip went byte by byte: rows x 12 dependent byte loads by one
+    // workgroup at the tail of the launch -- 131 us against 88 for the 2050-pixel-wide image of the reference's sweep, half of whose
+    // sizes have widths = 2 mod 4.)
+    auto strip_kind = [&](int uu) { const int ss = uu % nstrips; return aligned8 == 0 ? 0 : ((ss + 1) * G <= cols ? 1 : (rows > 1 ? 2 : 0)); };
     // pieces [k0, k1) of strip uu
     auto issue_strip = [&](int uu, int k0, int k1) {
-        if (!strip_fast(uu)) return;
+        const int kind = strip_kind(uu);
+        if (kind == 0) return;
         const int ff = uu / nstrips, ss = uu - ff * nstrips;
         const uint8_t* base = src + static_cast<size_t>(ff) * frame_bytes + static_cast<size_t>(ss) * RB;
         const int t0 = wr_opaque(tid);
@@ -413,7 +419,9 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
             if (k < k0 || k >= k1) continue;
             int idx = t0 + T * k;
             idx = idx < npiece ? idx : npiece - 1;              // unconditional loads: all in flight together
-            const int r = idx / PIECES, d = idx - r * PIECES;
+            int r = idx / PIECES;
+            const int d = idx - r * PIECES;
+            r = (kind == 2 && r == rows - 1) ? r - 1 : r;       // (the last row of a ragged strip is fetched byte by byte: commit_strip)
 #ifdef WR_ABL_NOLOAD
             pfu[k] = wr_piece(static_cast<unsigned>(r + d));
             (void)base;
@@ -430,7 +438,8 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
         }
     };
     auto commit_strip = [&](int uu) {
-        if (strip_fast(uu)) {
+        const int kind = strip_kind(uu);
+        if (kind == 1) {
 #pragma unroll
             for (int k = 0; k < KU; ++k) {
                 const int idx = tid + T * k;
@@ -440,6 +449,28 @@ __global__ __launch_bounds__(T) void wr_colpass_u8(const uint8_t* __restrict__ s
 #pragma unroll
                     for (int w = 0; w < PD; ++w) o[w] = pfu[k][w];
                 }
+            }
+        } else if (kind == 2) {
+            const int ff = uu / nstrips, ss = uu - ff * nstrips;
+            const int vb = (cols - ss * G) * CH;                 // bytes of a strip row that lie inside the image
+#pragma unroll
+            for (int k = 0; k < KU; ++k) {
+                const int idx = tid + T * k;
+                const int r = idx / PIECES, d = idx - r * PIECES;
+                if (idx < npiece && r < rows - 1) {
+                    unsigned* o = reinterpret_cast<unsigned*>(stage + r * RS + PB * d);
+                    const int nv = min(max(vb - PB * d, 0), PB);
+#pragma unroll
+                    for (int w = 0; w < PD; ++w) {
+                        const int keep = min(max(nv - 4 * w, 0), 4);
+                        o[w] = pfu[k][w] & (keep >= 4 ? 0xffffffffu : ((1u << (8 * keep)) - 1u));
+                    }
+                }
+            }
+            const uint8_t* lastrow = src + static_cast<size_t>(ff) * frame_bytes + static_cast<size_t>(rows - 1) * cols * CH;
+            for (int b = tid; b < RB; b += T) {
+                const int col = ss * G + b / CH;
+                stage[(rows - 1) * RS + b] = col < cols ? lastrow[static_cast<size_t>(col) * CH + (b % CH)] : static_cast<uint8_t>(0);
             }
         } else {
             // ragged last strip or rows that are not 8-byte aligned: byte loads, columns beyond the image are zero
