@@ -182,7 +182,7 @@ def test_config2_frame_1080p_wave_resident(ctx):
     assert_u8_parity(got.cpu().numpy(), want, planes)
 
 
-@pytest.mark.parametrize("rows,cols,sigma", [(3300, 2200, 57.0), (3705, 1000, 30.0), (2900, 517, 44.0), (3600, 1283, 20.0)])
+@pytest.mark.parametrize("rows,cols,sigma", [(3300, 2200, 57.0), (3705, 1000, 30.0), (2900, 517, 44.0), (3600, 1283, 20.0), (3075, 2050, 55.45)])
 def test_long_columns_whole_image(ctx, rows, cols, sigma):
     """columns of 2561 .. 4096 padded points: the C = 2 column kernels (strips of 4 columns) and a row kernel reading 4-column strips,
     the whole image in one transform per line; ragged widths, quirk on"""
@@ -194,3 +194,19 @@ def test_long_columns_whole_image(ctx, rows, cols, sigma):
     got = ctx.pffft_(t, sigma, out=torch.empty_like(t), wave_resident=True)
     assert ctx.last_family() == 2
     assert_u8_parity(got.cpu().numpy(), want, planes)
+
+
+@pytest.mark.parametrize("rows,cols,sigma,wr", [(2700, 518, 44.0, True), (900, 1270, 30.0, True), (2700, 515, 44.0, True)])
+def test_ragged_last_strip_in_a_batch(ctx, rows, cols, sigma, wr):
+    """widths that are no multiple of the column kernels' strip (4 or 8 columns), two frames per call: the last strip's pieces reach
+    into the next row -- and, in its last row, into the next frame or past the batch -- so that row is fetched byte by byte and the
+    bytes right of the image are masked (wr_kernels.hpp: strip_kind); each frame equals the frame blurred alone and the oracle"""
+    torch = _torch()
+    from oracle import oracle as O
+    frames = np.stack([_rand_img(rows, cols, 5 * rows + cols + i) for i in range(2)])
+    t = torch.from_numpy(frames).cuda()
+    got = ctx.pffft_(t, sigma, out=torch.empty_like(t), wave_resident=wr).cpu().numpy()
+    assert ctx.last_family() == 2
+    for i in range(2):
+        want, planes = O.pffft_blur_u8c3_f64(frames[i], sigma, True, want_planes=True)
+        assert_u8_parity(got[i], want, planes)
