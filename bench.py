@@ -415,7 +415,7 @@ def roofline_record(family, tm, steps, rows, cols, sz, copy_gbs):
         rl = {
             "bound": "mfma", "kernel": name, "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-            "avg_launch_ms": {name: round(k_ms, 4), "side kernels per step (the quirk's pre-pass with the edge strips, its term kernel; instrumented pass)": round(side_ms, 4)},
+            "avg_launch_ms": {name: round(k_ms, 4), "side kernels per step (the quirk's pre-pass with the edge strips; instrumented pass)": round(side_ms, 4)},
             "frames_per_launch": fpl,
             "flops_per_launch": shape["flops"], "mfma_instructions_per_launch": shape["mfma_instructions"], "tasks": shape["tasks"],
             "useful_flop_frac": round((2 * sz["pad"] + 1) / (16.0 * shape["nkb"]), 4),     # taps / window positions the products cover
