@@ -6,6 +6,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -310,3 +311,12 @@ def test_bench_model_of_the_fused_launch():
     assert one["tasks"] == 240 and one["segments_per_strip"] == 8
     wide = bench.fused_launch_shape(2160, 3840, 165, 8)
     assert wide["nkb"] == 23 and wide["tasks"] == 720
+
+
+def test_staging_addresses_of_the_fused_kernel_stay_inside_their_buffers():
+    """tools/fx_staging_addresses.py mirrors fx_blur_u8's staging loads (strip / image resources, fx_strip_range, the clamp of the
+    lanes past the window): over its list of shapes and window sizes no load may fall outside the frame or the written part of a
+    strip (round 4: a clamp that pointed before the frame hung the GPU test of the first version)"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, "tools", "fx_staging_addresses.py")], capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and p.stdout.strip().splitlines()[-1] == "bad 0", p.stdout[-500:] + p.stderr[-500:]
